@@ -1,0 +1,241 @@
+/*
+ * rcc.h -- C ABI of the MI355X-native calibration-target detection + pose hot path.
+ *
+ * This is the drop-in boundary for the per-frame path of Virtana/robot_camera_calibration
+ * (SURVEY.md section 8(b)).  The reference has no function API for this path; it has
+ *   (1) a ROS topic:  nh.subscribe("tag_detections", 1, aprilDetection)
+ *         real_preprocessing/src/corner_detections.cpp:78, callback :41-65, which reads per
+ *         detection  size[0] (:48), id[0] (:49), pixel_corners_x/y[0..3] (:53-54);
+ *   (2) one solver call:  cv::solvePnP(obj_pts, img_pts, kcam_matrix, kdistCoeffs, rvec, tvec,
+ *         false, CV_ITERATIVE)   real_preprocessing/src/camera_pose.cpp:163
+ *       with the corner order bl,br,tr,tl (:152-155) and object points (+-size/2, z=0) (:158-161),
+ *       followed by cv::Rodrigues (:164);
+ *   (3) intrinsics as 9 row-major doubles + 5 plumb-bob doubles
+ *         real_preprocessing/src/camera_pose.cpp:55-68.
+ * Each entry point below names the reference interface it stands in for.
+ *
+ * Rules of the boundary: extern "C", plain pointers and sizes, POD structs with explicit sizes,
+ * int status returns (0 = ok, <0 = error), nothing thrown across it, no torch types.
+ * One handle per GPU per thread; handles are not internally locked; distinct handles are independent.
+ */
+#ifndef RCC_H_
+#define RCC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCC_ABI_VERSION 1
+
+/* ---- status codes -------------------------------------------------------------------------- */
+enum {
+  RCC_OK = 0,
+  RCC_ERR_ARG = -1,          /* null pointer, bad size, bad enum */
+  RCC_ERR_UNSUPPORTED = -2,  /* valid request this build does not implement */
+  RCC_ERR_DEVICE = -3,       /* HIP runtime error; see rcc_last_device_error */
+  RCC_ERR_CAPACITY = -4,     /* nframes / ntargets exceeds what the handle was created for */
+  RCC_ERR_NOMEM = -5
+};
+
+/* ---- enums --------------------------------------------------------------------------------- */
+enum { RCC_PIX_MONO8 = 0, RCC_PIX_BGR8 = 1 };
+/* distortion model of D[]: plumb-bob = (k1,k2,p1,p2,k3) as in camera_pose.cpp:39,64;
+ * fisheye = (k1..k4), an extension the reference does not have. */
+enum { RCC_DIST_NONE = 0, RCC_DIST_PLUMB_BOB = 1, RCC_DIST_FISHEYE = 2 };
+enum { RCC_TARGET_CHECKERBOARD = 0, RCC_TARGET_FIDUCIAL = 1 };
+enum { RCC_MEM_HOST = 0, RCC_MEM_DEVICE = 1 };
+
+/* per-frame status word (bit flags) */
+enum {
+  RCC_FRAME_OK = 0,
+  RCC_FRAME_CAND_OVERFLOW = 1, /* more Harris candidates than max_candidates: frame yields nothing */
+  RCC_FRAME_NOT_FOUND = 2,     /* no complete target found */
+  RCC_FRAME_KEPT_OVERFLOW = 4  /* more validated corners than max_kept: frame yields nothing */
+};
+
+/* per-target PnP status */
+enum {
+  RCC_PNP_OK = 0,
+  RCC_PNP_TOO_FEW = 1,    /* fewer than 4 points */
+  RCC_PNP_NONPLANAR = 2,  /* object points not coplanar: outside the reference's use (planar tags) */
+  RCC_PNP_DEGENERATE = 3  /* non-finite homography; OpenCV falls back to R=I,t=0, so do we */
+};
+
+#define RCC_MAX_BOARD_CORNERS 256
+
+/* ---- configuration (POD) ------------------------------------------------------------------- */
+typedef struct rcc_config {
+  uint32_t struct_size;   /* = sizeof(rcc_config); checked by rcc_create */
+  uint32_t abi_version;   /* = RCC_ABI_VERSION */
+
+  /* image geometry */
+  int32_t width, height;
+  int32_t stride_bytes;   /* bytes between rows of one input frame, >= width*channels */
+  int32_t pixfmt;         /* RCC_PIX_* */
+  int64_t frame_bytes;    /* bytes between consecutive frames of a batch, >= stride_bytes*height */
+
+  /* intrinsics: K row-major 3x3 and D exactly as camera_pose.cpp:59-64 loads them */
+  double K[9];
+  int32_t dist_model;     /* RCC_DIST_* */
+  int32_t undistort;      /* 1: per-pixel undistortion in the ingest pass, PnP then runs with D=0;
+                             0: detector runs on the raw image, PnP uses D (the reference's way,
+                                camera_pose.cpp:163) */
+  double D[8];
+
+  /* a3 adaptive threshold (apriltag tile min/max form) */
+  int32_t thr_min_contrast; /* 5 */
+
+  /* a4 corner extraction */
+  int32_t harris_thresh;    /* accept R >= this (integer Harris response) */
+  int32_t cand_margin;      /* candidates keep this many pixels from the image border (>= 8) */
+  int32_t max_candidates;   /* per-frame capacity of the dense pass's output list */
+  int32_t nms_radius;       /* list-level suppression radius (Chebyshev), pixels */
+  int32_t xj_check;         /* 1: keep only X-junctions (ring test on the threshold map) */
+  int32_t max_kept;         /* per-frame capacity after suppression + validation (<= 256) */
+
+  /* a5 sub-pixel refinement (cornerSubPix form) */
+  int32_t subpix_win;       /* half window w: (2w+1)^2 samples; 1..7 */
+  int32_t subpix_max_iter;  /* 30 */
+  double  subpix_eps;       /* stop when the step is shorter than this, pixels */
+
+  /* a6 target */
+  int32_t target_kind;      /* RCC_TARGET_* */
+  int32_t board_cols, board_rows; /* inner corners, e.g. 8 x 6 (real_preprocessing/README.md:57) */
+  double  board_square;     /* metres, e.g. 0.108 */
+  int32_t board_id;         /* id reported for the board */
+  int32_t max_targets;      /* result slots per frame */
+
+  /* a7 */
+  int32_t reference_mode;   /* 1: truncate sub-pixel corners to int before PnP, as
+                               corner_detections.cpp:53-54 does */
+  int32_t pnp_use_mfma;     /* 1: f64 MFMA for the JtJ/Jte blocks of the wave-per-target solver */
+
+  /* resources */
+  int32_t device;           /* HIP device ordinal */
+  int32_t batch_capacity;   /* max frames per rcc_detect_batch call */
+  int32_t reserved[8];
+} rcc_config;
+
+/* ---- result records (POD) ------------------------------------------------------------------ */
+/* One record per detected target: what apriltag_ros::AprilTagDetection carries to
+ * corner_detections.cpp:46-56 (id, size, four pixel corners) plus the pose camera_pose.cpp:163-164
+ * computes from them.  Corner order is bl, br, tr, tl (camera_pose.cpp:123-126,152-155). */
+typedef struct rcc_detection {
+  int32_t frame;          /* index within the batch */
+  int32_t id;             /* targetID */
+  int32_t hamming;        /* fiducial decode distance; 0 for the board */
+  int32_t ncorners;       /* 4 for a fiducial, cols*rows for the board */
+  double  size;           /* metres; side of the square spanned by corners[] in the object frame
+                             (fiducial) or board_square (board) */
+  double  corners[4][2];  /* bl, br, tr, tl pixel coordinates (sub-pixel; the reference casts to int) */
+  double  rvec[3];        /* cam_T_target rotation vector, as solvePnP returns it */
+  double  tvec[3];
+  double  rms;            /* RMS reprojection error, pixels */
+  int32_t pnp_status;     /* RCC_PNP_* */
+  int32_t pnp_iters;
+} rcc_detection;
+
+/* Per-frame board output: all inner corners in row-major order of the board (row 0 first). */
+typedef struct rcc_frame_corners {
+  int32_t status;         /* RCC_FRAME_* flags */
+  int32_t ncand;          /* dense-pass candidates */
+  int32_t nkept;          /* after suppression + X-junction validation */
+  int32_t ncorners;       /* 0 or cols*rows */
+  int32_t px[RCC_MAX_BOARD_CORNERS][2]; /* integer candidate pixel (x,y): the bit-exact "corner index" */
+  double  xy[RCC_MAX_BOARD_CORNERS][2]; /* refined sub-pixel position */
+} rcc_frame_corners;
+
+typedef struct rcc_handle rcc_handle;
+
+/* ---- lifecycle ----------------------------------------------------------------------------- */
+void rcc_default_config(rcc_config* cfg);  /* fills every field with the documented defaults */
+int  rcc_create(const rcc_config* cfg, rcc_handle** out);
+void rcc_destroy(rcc_handle* h);
+const char* rcc_status_string(int status);
+const char* rcc_last_device_error(const rcc_handle* h);
+int  rcc_abi_version(void);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* Stands in for the external detector node that publishes "tag_detections"
+ * (real_preprocessing/README.md:65; consumer corner_detections.cpp:41-56,78) plus the per-target
+ * pose of camera_pose.cpp:163-164.
+ *   frames     nframes images, frame_bytes apart, in host or device memory (frames_mem)
+ *   det        out, capacity nframes*max_targets records, host memory; *ndet receives the count,
+ *              records ordered by (frame, slot)
+ *   corners    out, optional (may be NULL): nframes records, host memory
+ *   stream     hipStream_t or NULL for the handle's own stream
+ * The call is synchronous with respect to its outputs. */
+int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t frames_mem,
+                     rcc_detection* det, int32_t* ndet, rcc_frame_corners* corners, void* stream);
+
+/* 1:1 stand-in for cv::solvePnP(obj, img, K, D, rvec, tvec, false, CV_ITERATIVE) at
+ * camera_pose.cpp:163, batched over targets.  K/D NULL means the handle's.
+ *   obj    sum(npts) x 3 doubles, img  sum(npts) x 2 doubles, targets concatenated
+ *   npts   ntargets counts
+ *   rvec, tvec  ntargets x 3; rms, status, iters ntargets (rms/status/iters may be NULL)
+ * All pointers host memory. */
+int rcc_solve_pnp_batch(rcc_handle* h, const double* obj, const double* img, const int32_t* npts,
+                        int32_t ntargets, const double* K, const double* D, int32_t dist_model,
+                        double* rvec, double* tvec, double* rms, int32_t* status, int32_t* iters);
+
+/* cv::Rodrigues both ways (camera_pose.cpp:93,116,164; opt_visualization.cpp:36), batched, host
+ * pointers; computed on the device. */
+int rcc_rodrigues_v2m_batch(rcc_handle* h, const double* rvec, int32_t n, double* R9);
+int rcc_rodrigues_m2v_batch(rcc_handle* h, const double* R9, int32_t n, double* rvec);
+
+/* ---- stage-level entry points (device pointers; used by the parity tests and the bench) ------ */
+/* a1+a2: ingest = BGR->grey (+ undistort when cfg.undistort).  src/dst device pointers;
+ * dst is nframes tightly packed width*height u8 images. */
+int rcc_stage_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey, void* stream);
+/* a3+a4 dense pass: grey -> threshold map {0,127,255} + candidate list.
+ *   d_bin       nframes*width*height u8
+ *   d_cand      nframes*max_candidates entries {int16 x, int16 y, int32 score}, unordered
+ *   d_cand_count nframes int32 (true count, may exceed max_candidates) */
+int rcc_stage_threshold_corner(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_bin,
+                               void* d_cand, void* d_cand_count, void* stream);
+/* variant selector for the dense pass: 0 = generic LDS-staged kernel, 1 = row-marching fast kernel
+ * (needs width % 64 == 0); -1 = automatic.  Returns the previous value. */
+int rcc_set_dense_variant(rcc_handle* h, int variant);
+int rcc_set_ingest_variant(rcc_handle* h, int variant);
+/* a4 list stage + a5 + a6 + a7 for the board: consumes the dense pass outputs, fills per-frame
+ * device records (layout = rcc_frame_corners / rcc_detection), then copies to host. */
+int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, const void* d_cand,
+                      const void* d_cand_count, int32_t nframes, rcc_detection* det, int32_t* ndet,
+                      rcc_frame_corners* corners, void* stream);
+
+/* timings of the last rcc_detect_batch / stage call, milliseconds, measured with HIP events on the
+ * stream the kernels were launched on: [0] ingest, [1] dense threshold+corner, [2] list+subpix+grid,
+ * [3] pnp, [4] d2h.  Returns the number of slots written. */
+int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n);
+/* Launch the dense pass `reps` times back to back and return the mean kernel time in ms measured
+ * with HIP events on the launch stream (bench.py's roofline leg). */
+int rcc_time_dense(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_bin, void* d_cand,
+                   void* d_cand_count, int32_t reps, float* mean_ms);
+int rcc_time_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey,
+                    int32_t reps, float* mean_ms);
+
+/* ---- synthetic camera (stands where rviz_simulator's missing camera.h was meant to be,
+ *      rviz_simulator/include/rviz_simulator/target.h:40) --------------------- */
+typedef struct rcc_synth_params {
+  uint32_t struct_size;
+  int32_t  board_cols, board_rows;  /* inner corners */
+  double   board_square;
+  int32_t  margin_squares;          /* white quiet zone around the board, in squares (1) */
+  int32_t  supersample;             /* s x s samples per pixel (4) */
+  double   noise_sigma;             /* additive Gaussian noise, LSB (2) */
+  uint64_t seed;                    /* frame f uses seed + f (0xC0FFEE) */
+  int32_t  black, white, background;/* 20, 235, 128 */
+  int32_t  reserved[5];
+} rcc_synth_params;
+
+/* Render nframes frames of the handle's geometry/intrinsics into d_frames (device), one pose per
+ * frame: poses = nframes x 6 doubles (rvec, tvec of cam_T_target), host memory. */
+int rcc_synth_render_batch(rcc_handle* h, const rcc_synth_params* sp, const double* poses,
+                           int32_t nframes, int32_t first_frame_index, void* d_frames, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCC_H_ */

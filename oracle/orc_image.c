@@ -1,0 +1,361 @@
+/*
+ * orc_image.c -- CPU oracle, image stages a1..a4.  TEST INFRASTRUCTURE.
+ *
+ * None of this arithmetic exists in /root/reference: the reference subscribes to the output of an
+ * external detector (real_preprocessing/src/corner_detections.cpp:4,41,78) that it launches on
+ * image_raw (real_preprocessing/README.md:65).  The stages follow SURVEY.md appendix B, the
+ * restated published definitions; where the build had to choose, the choice is marked [B] and
+ * repeated in DESIGN.md.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+#include "orc.h"
+
+/* ------------------------------------------------------------------------------------------------
+ * a1  BGR8 -> grey.  SURVEY appendix B.1: Y = (B*1868 + G*9617 + R*4899 + (1<<13)) >> 14
+ * (the image the detector receives is bgr8 from cv_camera, README.md:64-65).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_bgr_to_grey(const uint8_t* bgr, int w, int h, int stride, uint8_t* grey)
+{
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* row = bgr + (size_t)y * stride;
+    for (int x = 0; x < w; ++x) {
+      int b = row[3 * x], g = row[3 * x + 1], r = row[3 * x + 2];
+      grey[(size_t)y * w + x] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * atan for r >= 0 from +,-,*,/ only, so that a device restatement is bit-identical [B].
+ * Reduction: r>1 -> 1/r ; t>tan(pi/8) -> (t-1)/(t+1) ; odd Taylor series, 24 terms, Horner.
+ * ---------------------------------------------------------------------------------------------- */
+double orc_atan_pos(double r)
+{
+  const double PI_2 = 1.57079632679489661923, PI_4 = 0.78539816339744830962;
+  const double T8 = 0.41421356237309504880;
+  int flip = 0;
+  double t = r;
+  if (t > 1.0) { t = 1.0 / t; flip = 1; }
+  double base = 0.0;
+  if (t > T8) { t = (t - 1.0) / (t + 1.0); base = PI_4; }
+  double z = t * t;
+  double s = 0.0;
+  for (int k = 23; k >= 0; --k) {
+    double c = 1.0 / (double)(2 * k + 1);
+    if (k & 1) c = -c;
+    s = s * z + c;
+  }
+  double a = base + t * s;
+  if (flip) a = PI_2 - a;
+  return a;
+}
+
+static int32_t sat_rint_i32(double v)
+{
+  double r = rint(v);
+  if (!(r > -2147483648.0)) return INT32_MIN;  /* also catches NaN */
+  if (r > 2147483647.0) return INT32_MAX;
+  return (int32_t)r;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a2  undistortion map, Q5 fixed point.  SURVEY appendix B.2 (initUndistortRectifyMap with
+ * newK = K, R = I).  K and D are laid out as camera_pose.cpp:59-64 loads them: K row-major 3x3,
+ * D = (k1,k2,p1,p2,k3).  Fisheye D = (k1..k4) is an extension [B]; the reference has none.
+ * Every line is one rounded IEEE operation (or a short chain written in evaluation order).
+ * ---------------------------------------------------------------------------------------------- */
+void orc_undistort_map_q5(const double K[9], int dist_model, const double D[8], int w, int h,
+                          int32_t* mapx, int32_t* mapy)
+{
+  const double fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+  for (int v = 0; v < h; ++v) {
+    for (int u = 0; u < w; ++u) {
+      double x = ((double)u - cx) / fx;
+      double y = ((double)v - cy) / fy;
+      double xs, ys;
+      if (dist_model == RCC_DIST_PLUMB_BOB) {
+        const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4];
+        double x2 = x * x, y2 = y * y;
+        double r2 = x2 + y2;
+        double _2xy = (2.0 * x) * y;
+        double kr = k3 * r2;
+        kr = kr + k2;
+        kr = kr * r2;
+        kr = kr + k1;
+        kr = kr * r2;
+        kr = 1.0 + kr;
+        double tx = 2.0 * x2;
+        tx = r2 + tx;
+        double ty = 2.0 * y2;
+        ty = r2 + ty;
+        double xd = x * kr;
+        double a = p1 * _2xy;
+        xd = xd + a;
+        a = p2 * tx;
+        xd = xd + a;
+        double yd = y * kr;
+        a = p1 * ty;
+        yd = yd + a;
+        a = p2 * _2xy;
+        yd = yd + a;
+        xs = fx * xd;
+        xs = xs + cx;
+        ys = fy * yd;
+        ys = ys + cy;
+      } else if (dist_model == RCC_DIST_FISHEYE) {
+        const double k1 = D[0], k2 = D[1], k3 = D[2], k4 = D[3];
+        double x2 = x * x, y2 = y * y;
+        double r = sqrt(x2 + y2);
+        double th = orc_atan_pos(r);
+        double t2 = th * th;
+        double p = k4 * t2;
+        p = p + k3;
+        p = p * t2;
+        p = p + k2;
+        p = p * t2;
+        p = p + k1;
+        p = p * t2;
+        p = 1.0 + p;
+        double thd = th * p;
+        double s = (r > 1e-8) ? thd / r : 1.0;
+        xs = fx * x;
+        xs = xs * s;
+        xs = xs + cx;
+        ys = fy * y;
+        ys = ys * s;
+        ys = ys + cy;
+      } else {
+        xs = (double)u;
+        ys = (double)v;
+      }
+      mapx[(size_t)v * w + u] = sat_rint_i32(xs * 32.0);
+      mapy[(size_t)v * w + u] = sat_rint_i32(ys * 32.0);
+    }
+  }
+}
+
+/* remap, INTER_LINEAR with 5 fractional bits, BORDER_CONSTANT 0 (appendix B.2).  With 5-bit
+ * fractions the Q15 weight table is exactly 32*(32-fx)(32-fy) etc. and sums to 32768, so
+ * (sum w*p + (1<<14)) >> 15 == (sum wq*p + 512) >> 10 with wq the 10-bit products. */
+void orc_remap_q5(const uint8_t* src, int w, int h, int stride, const int32_t* mapx,
+                  const int32_t* mapy, uint8_t* dst)
+{
+  for (int v = 0; v < h; ++v) {
+    for (int u = 0; u < w; ++u) {
+      int32_t X = mapx[(size_t)v * w + u], Y = mapy[(size_t)v * w + u];
+      int32_t ix = X >> 5, iy = Y >> 5;
+      int32_t fx = X & 31, fy = Y & 31;
+      int p00 = 0, p01 = 0, p10 = 0, p11 = 0;
+      if (iy >= 0 && iy < h) {
+        if (ix >= 0 && ix < w) p00 = src[(size_t)iy * stride + ix];
+        if (ix + 1 >= 0 && ix + 1 < w) p01 = src[(size_t)iy * stride + ix + 1];
+      }
+      if (iy + 1 >= 0 && iy + 1 < h) {
+        if (ix >= 0 && ix < w) p10 = src[(size_t)(iy + 1) * stride + ix];
+        if (ix + 1 >= 0 && ix + 1 < w) p11 = src[(size_t)(iy + 1) * stride + ix + 1];
+      }
+      int acc = (32 - fx) * (32 - fy) * p00 + fx * (32 - fy) * p01 + (32 - fx) * fy * p10 +
+                fx * fy * p11;
+      dst[(size_t)v * w + u] = (uint8_t)((acc + 512) >> 10);
+    }
+  }
+}
+
+/* a1+a2 for one frame: grey first, then remap of the grey image [B] (the order is the build's
+ * choice: the reference never undistorts pixels). */
+int orc_ingest(const rcc_config* cfg, const uint8_t* frame, uint8_t* grey_out)
+{
+  const int w = cfg->width, h = cfg->height;
+  uint8_t* grey = grey_out;
+  uint8_t* tmp = NULL;
+  const int undist = cfg->undistort && cfg->dist_model != RCC_DIST_NONE;
+  if (undist) {
+    tmp = (uint8_t*)malloc((size_t)w * h);
+    if (!tmp) return RCC_ERR_NOMEM;
+    grey = tmp;
+  }
+  if (cfg->pixfmt == RCC_PIX_BGR8) {
+    orc_bgr_to_grey(frame, w, h, cfg->stride_bytes, grey);
+  } else {
+    for (int y = 0; y < h; ++y) memcpy(grey + (size_t)y * w, frame + (size_t)y * cfg->stride_bytes, w);
+  }
+  if (undist) {
+    int32_t* mx = (int32_t*)malloc(sizeof(int32_t) * (size_t)w * h);
+    int32_t* my = (int32_t*)malloc(sizeof(int32_t) * (size_t)w * h);
+    if (!mx || !my) { free(mx); free(my); free(tmp); return RCC_ERR_NOMEM; }
+    orc_undistort_map_q5(cfg->K, cfg->dist_model, cfg->D, w, h, mx, my);
+    orc_remap_q5(tmp, w, h, w, mx, my, grey_out);
+    free(mx); free(my); free(tmp);
+  }
+  return RCC_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a3  apriltag tile threshold, SURVEY appendix B.3.  Tiles are 4x4; each tile takes the max of
+ * max / min of min over its 3x3 tile neighbourhood (clamped at the borders); per pixel:
+ * max-min < min_contrast -> 127, else v > min + (max-min)/2 ? 255 : 0.
+ * [B] ragged sizes: the last tile of a row/column is extended to the image edge (its extra
+ * pixels contribute to its min/max), so every pixel belongs to exactly one tile.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_threshold_tiles(const uint8_t* grey, int w, int h, int min_contrast, uint8_t* bin)
+{
+  int tw = w / 4, th = h / 4;
+  if (tw < 1) tw = 1;
+  if (th < 1) th = 1;
+  uint8_t* tmin = (uint8_t*)malloc((size_t)tw * th);
+  uint8_t* tmax = (uint8_t*)malloc((size_t)tw * th);
+  uint8_t* dmin = (uint8_t*)malloc((size_t)tw * th);
+  uint8_t* dmax = (uint8_t*)malloc((size_t)tw * th);
+  memset(tmin, 255, (size_t)tw * th);
+  memset(tmax, 0, (size_t)tw * th);
+  for (int y = 0; y < h; ++y) {
+    int ty = y >> 2; if (ty > th - 1) ty = th - 1;
+    for (int x = 0; x < w; ++x) {
+      int tx = x >> 2; if (tx > tw - 1) tx = tw - 1;
+      uint8_t v = grey[(size_t)y * w + x];
+      size_t t = (size_t)ty * tw + tx;
+      if (v < tmin[t]) tmin[t] = v;
+      if (v > tmax[t]) tmax[t] = v;
+    }
+  }
+  for (int ty = 0; ty < th; ++ty)
+    for (int tx = 0; tx < tw; ++tx) {
+      int mn = 255, mx = 0;
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          int yy = ty + dy, xx = tx + dx;
+          if (yy < 0 || yy >= th || xx < 0 || xx >= tw) continue;
+          int a = tmin[(size_t)yy * tw + xx], b = tmax[(size_t)yy * tw + xx];
+          if (a < mn) mn = a;
+          if (b > mx) mx = b;
+        }
+      dmin[(size_t)ty * tw + tx] = (uint8_t)mn;
+      dmax[(size_t)ty * tw + tx] = (uint8_t)mx;
+    }
+  for (int y = 0; y < h; ++y) {
+    int ty = y >> 2; if (ty > th - 1) ty = th - 1;
+    for (int x = 0; x < w; ++x) {
+      int tx = x >> 2; if (tx > tw - 1) tx = tw - 1;
+      int mn = dmin[(size_t)ty * tw + tx], mx = dmax[(size_t)ty * tw + tx];
+      int v = grey[(size_t)y * w + x];
+      uint8_t o;
+      if (mx - mn < min_contrast) o = 127;
+      else o = (v > mn + (mx - mn) / 2) ? 255 : 0;
+      bin[(size_t)y * w + x] = o;
+    }
+  }
+  free(tmin); free(tmax); free(dmin); free(dmax);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a4  Harris response, all-integer form [B] of SURVEY appendix B.4 (cornerHarris structure:
+ * Sobel 3x3 -> structure tensor over blockSize 5 -> det - k*trace^2):
+ *   gx, gy = Sobel3x3 >> 3          (arithmetic shift; grey levels per pixel, in [-128,127])
+ *   pxx = (gx*gx) >> 4, pxy = (gx*gy) >> 4, pyy = (gy*gy) >> 4      (floor)
+ *   A,B,C  = 5x5 box sums of pxx,pxy,pyy                              (|.| <= 25600)
+ *   R      = A*C - B*B - ((A+C)^2 >> 4)                               (k = 1/16), fits int32
+ * R is defined where the 7x7 support lies inside the image; elsewhere INT32_MIN.
+ * ---------------------------------------------------------------------------------------------- */
+void orc_harris_response(const uint8_t* g, int w, int h, int32_t* R)
+{
+  size_t n = (size_t)w * h;
+  int16_t* pxx = (int16_t*)calloc(n, sizeof(int16_t));
+  int16_t* pxy = (int16_t*)calloc(n, sizeof(int16_t));
+  int16_t* pyy = (int16_t*)calloc(n, sizeof(int16_t));
+  for (size_t i = 0; i < n; ++i) R[i] = INT32_MIN;
+  for (int y = 1; y < h - 1; ++y)
+    for (int x = 1; x < w - 1; ++x) {
+      const uint8_t* p = g + (size_t)y * w + x;
+      int sx = (p[-w + 1] + 2 * p[1] + p[w + 1]) - (p[-w - 1] + 2 * p[-1] + p[w - 1]);
+      int sy = (p[w - 1] + 2 * p[w] + p[w + 1]) - (p[-w - 1] + 2 * p[-w] + p[-w + 1]);
+      int gx = sx >> 3, gy = sy >> 3;
+      pxx[(size_t)y * w + x] = (int16_t)((gx * gx) >> 4);
+      pxy[(size_t)y * w + x] = (int16_t)((gx * gy) >> 4);
+      pyy[(size_t)y * w + x] = (int16_t)((gy * gy) >> 4);
+    }
+  for (int y = 3; y < h - 3; ++y)
+    for (int x = 3; x < w - 3; ++x) {
+      int32_t A = 0, B = 0, C = 0;
+      for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) {
+          size_t i = (size_t)(y + dy) * w + (x + dx);
+          A += pxx[i]; B += pxy[i]; C += pyy[i];
+        }
+      uint32_t tr = (uint32_t)(A + C);
+      int32_t r = A * C - B * B - (int32_t)((tr * tr) >> 4);
+      R[(size_t)y * w + x] = r;
+    }
+  free(pxx); free(pxy); free(pyy);
+}
+
+/* a4 dense selection [B]: R >= thresh, strict 3x3 local maximum with scan-order tie break
+ * (greater than the four neighbours that precede it in (y,x) order, not less than the four that
+ * follow), at least `margin` pixels from every border.  Output sorted by (y,x). */
+int orc_harris_candidates(const int32_t* R, int w, int h, int thresh, int margin, orc_cand* out, int cap)
+{
+  int n = 0;
+  if (margin < 4) margin = 4;
+  for (int y = margin; y < h - margin; ++y)
+    for (int x = margin; x < w - margin; ++x) {
+      const int32_t* p = R + (size_t)y * w + x;
+      int32_t r = *p;
+      if (r < thresh) continue;
+      if (!(r > p[-w - 1] && r > p[-w] && r > p[-w + 1] && r > p[-1])) continue;
+      if (!(r >= p[1] && r >= p[w - 1] && r >= p[w] && r >= p[w + 1])) continue;
+      if (n < cap) { out[n].x = (int16_t)x; out[n].y = (int16_t)y; out[n].score = r; }
+      ++n;
+    }
+  return n;
+}
+
+/* X-junction ring test [B] (appendix B.4 last sentence): 16 samples of the threshold map on a
+ * radius-5 ring; a checkerboard inner corner shows exactly 4 black/white transitions and no
+ * low-contrast (127) sample. */
+static const int8_t RING16[16][2] = {
+  { 5, 0}, { 5, 2}, { 4, 4}, { 2, 5}, { 0, 5}, {-2, 5}, {-4, 4}, {-5, 2},
+  {-5, 0}, {-5,-2}, {-4,-4}, {-2,-5}, { 0,-5}, { 2,-5}, { 4,-4}, { 5,-2}
+};
+
+int orc_xjunction_ring(const uint8_t* bin, int w, int h, int x, int y)
+{
+  if (x < 5 || y < 5 || x >= w - 5 || y >= h - 5) return 0;
+  int v[16];
+  for (int k = 0; k < 16; ++k) {
+    v[k] = bin[(size_t)(y + RING16[k][1]) * w + (x + RING16[k][0])];
+    if (v[k] == 127) return 0;
+  }
+  int tr = 0;
+  for (int k = 0; k < 16; ++k) tr += (v[k] != v[(k + 1) & 15]);
+  return tr == 4;
+}
+
+/* list-level suppression [B]: entry i survives iff no other entry j within Chebyshev distance
+ * nms_radius has a larger score (or an equal score and a smaller index).  Not greedy: decided
+ * against the full input list, so it is order-independent apart from the tie break.  Survivors
+ * are then ring-validated.  Input and output sorted by (y,x). */
+int orc_filter_candidates(const orc_cand* in, int n, const uint8_t* bin, int w, int h,
+                          int nms_radius, int xj_check, orc_cand* out, int cap)
+{
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    int keep = 1;
+    for (int j = 0; j < n && keep; ++j) {
+      if (j == i) continue;
+      int dx = in[j].x - in[i].x, dy = in[j].y - in[i].y;
+      if (dx < 0) dx = -dx;
+      if (dy < 0) dy = -dy;
+      if (dx <= nms_radius && dy <= nms_radius) {
+        if (in[j].score > in[i].score || (in[j].score == in[i].score && j < i)) keep = 0;
+      }
+    }
+    if (keep && xj_check) keep = orc_xjunction_ring(bin, w, h, in[i].x, in[i].y);
+    if (keep) {
+      if (m < cap) out[m] = in[i];
+      ++m;
+    }
+  }
+  return m;
+}

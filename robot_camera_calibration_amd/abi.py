@@ -1,0 +1,115 @@
+"""ctypes mirror of include/rcc.h (the C-ABI boundary).
+
+Plain data only: struct layouts, enums and argument marshalling.  No compute happens here.
+The reference interface each entry point stands in for is cited in include/rcc.h
+(real_preprocessing/src/corner_detections.cpp:41-56,78 and camera_pose.cpp:55-68,132-173).
+"""
+import ctypes as C
+
+RCC_ABI_VERSION = 1
+
+# status
+RCC_OK, RCC_ERR_ARG, RCC_ERR_UNSUPPORTED, RCC_ERR_DEVICE, RCC_ERR_CAPACITY, RCC_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+# enums
+RCC_PIX_MONO8, RCC_PIX_BGR8 = 0, 1
+RCC_DIST_NONE, RCC_DIST_PLUMB_BOB, RCC_DIST_FISHEYE = 0, 1, 2
+RCC_TARGET_CHECKERBOARD, RCC_TARGET_FIDUCIAL = 0, 1
+RCC_MEM_HOST, RCC_MEM_DEVICE = 0, 1
+RCC_FRAME_OK, RCC_FRAME_CAND_OVERFLOW, RCC_FRAME_NOT_FOUND, RCC_FRAME_KEPT_OVERFLOW = 0, 1, 2, 4
+RCC_PNP_OK, RCC_PNP_TOO_FEW, RCC_PNP_NONPLANAR, RCC_PNP_DEGENERATE = 0, 1, 2, 3
+RCC_MAX_BOARD_CORNERS = 256
+
+
+class rcc_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
+        ("width", C.c_int32), ("height", C.c_int32), ("stride_bytes", C.c_int32), ("pixfmt", C.c_int32),
+        ("frame_bytes", C.c_int64),
+        ("K", C.c_double * 9),
+        ("dist_model", C.c_int32), ("undistort", C.c_int32),
+        ("D", C.c_double * 8),
+        ("thr_min_contrast", C.c_int32),
+        ("harris_thresh", C.c_int32), ("cand_margin", C.c_int32), ("max_candidates", C.c_int32),
+        ("nms_radius", C.c_int32), ("xj_check", C.c_int32), ("max_kept", C.c_int32),
+        ("subpix_win", C.c_int32), ("subpix_max_iter", C.c_int32),
+        ("subpix_eps", C.c_double),
+        ("target_kind", C.c_int32), ("board_cols", C.c_int32), ("board_rows", C.c_int32),
+        ("board_square", C.c_double),
+        ("board_id", C.c_int32), ("max_targets", C.c_int32),
+        ("reference_mode", C.c_int32), ("pnp_use_mfma", C.c_int32),
+        ("device", C.c_int32), ("batch_capacity", C.c_int32),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
+class rcc_detection(C.Structure):
+    _fields_ = [
+        ("frame", C.c_int32), ("id", C.c_int32), ("hamming", C.c_int32), ("ncorners", C.c_int32),
+        ("size", C.c_double),
+        ("corners", (C.c_double * 2) * 4),
+        ("rvec", C.c_double * 3), ("tvec", C.c_double * 3),
+        ("rms", C.c_double),
+        ("pnp_status", C.c_int32), ("pnp_iters", C.c_int32),
+    ]
+
+
+class rcc_frame_corners(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("ncand", C.c_int32), ("nkept", C.c_int32), ("ncorners", C.c_int32),
+        ("px", (C.c_int32 * 2) * RCC_MAX_BOARD_CORNERS),
+        ("xy", (C.c_double * 2) * RCC_MAX_BOARD_CORNERS),
+    ]
+
+
+class rcc_synth_params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("board_cols", C.c_int32), ("board_rows", C.c_int32),
+        ("board_square", C.c_double),
+        ("margin_squares", C.c_int32), ("supersample", C.c_int32),
+        ("noise_sigma", C.c_double),
+        ("seed", C.c_uint64),
+        ("black", C.c_int32), ("white", C.c_int32), ("background", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
+class cand_entry(C.Structure):
+    """one dense-pass candidate: {int16 x, int16 y, int32 score} (rcc_stage_threshold_corner)"""
+    _fields_ = [("x", C.c_int16), ("y", C.c_int16), ("score", C.c_int32)]
+
+
+def default_synth_params(cols=8, rows=6, square=0.108, seed=0xC0FFEE, noise=2.0, supersample=4):
+    sp = rcc_synth_params()
+    sp.struct_size = C.sizeof(rcc_synth_params)
+    sp.board_cols, sp.board_rows, sp.board_square = cols, rows, square
+    sp.margin_squares, sp.supersample, sp.noise_sigma = 1, supersample, noise
+    sp.seed = seed
+    sp.black, sp.white, sp.background = 20, 235, 128
+    return sp
+
+
+def set_geometry(cfg, width, height, pixfmt=RCC_PIX_BGR8):
+    """Fill the image geometry and the SURVEY 8(d) synthetic intrinsics (fx=fy=0.9 W, centre)."""
+    ch = 3 if pixfmt == RCC_PIX_BGR8 else 1
+    cfg.width, cfg.height, cfg.pixfmt = width, height, pixfmt
+    cfg.stride_bytes = width * ch
+    cfg.frame_bytes = width * ch * height
+    for i in range(9):
+        cfg.K[i] = 0.0
+    cfg.K[0] = cfg.K[4] = 0.9 * width
+    cfg.K[2] = (width - 1) * 0.5
+    cfg.K[5] = (height - 1) * 0.5
+    cfg.K[8] = 1.0
+    return cfg
+
+
+def set_distortion(cfg, model, coeffs):
+    cfg.dist_model = model
+    for i in range(8):
+        cfg.D[i] = coeffs[i] if i < len(coeffs) else 0.0
+    return cfg
+
+
+PLUMB_BOB_DEFAULT = (-0.28, 0.07, 2e-4, -1e-4, 0.0)
+FISHEYE_DEFAULT = (-0.02, 0.005, -0.001, 0.0002)
