@@ -216,6 +216,14 @@ int rcc_time_dense(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_b
 int rcc_time_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey,
                     int32_t reps, float* mean_ms);
 
+/* test taps: copy the intermediate lists / images of the handle's last rcc_detect_batch to host
+ * memory (any pointer may be NULL).  pre/kept: nframes*256 entries {int16 x, int16 y, int32 score};
+ * pre_xy/kept_xy: nframes*256*2 doubles; cand: nframes*max_candidates entries. */
+int rcc_debug_fetch_lists(rcc_handle* h, int32_t nframes, void* pre, int32_t* npre, double* pre_xy,
+                          void* kept, double* kept_xy);
+int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin, void* cand,
+                           int32_t* cand_count);
+
 /* ---- synthetic camera (stands where rviz_simulator's missing camera.h was meant to be,
  *      rviz_simulator/include/rviz_simulator/target.h:40) --------------------- */
 typedef struct rcc_synth_params {

@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's interface for the detection + pose path, over the C ABI.
+
+The reference exposes this path as (i) a ROS topic carrying, per detection, id[0], size[0] and
+pixel_corners_x/y[0..3] (real_preprocessing/src/corner_detections.cpp:41-56,78) and (ii) one call
+cv::solvePnP(obj_pts, img_pts, K, D, rvec, tvec, false, CV_ITERATIVE) followed by cv::Rodrigues
+(real_preprocessing/src/camera_pose.cpp:163-164).  `Detector.detect` returns records with exactly
+those fields (+ pose); `Detector.solve_pnp` takes the arguments of the solver call in the same
+order and meaning.  Everything computes in librcc_hip.so (hand-written HIP, gfx950); there is no
+CPU fallback -- a missing library or device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBNAME = "librcc_hip.so"
+_lib = None
+
+
+class RccError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = "%s failed: %s (%d)" % (where, status_string(status), status)
+        if detail:
+            msg += " -- " + detail
+        super().__init__(msg)
+
+
+def library_path():
+    return os.path.join(_HERE, _LIBNAME)
+
+
+def load_library():
+    """Load the HIP implementation.  Raises if it has not been built (python __graft_entry__.py
+    build): the product path never substitutes anything for it."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')" % path)
+    L = C.CDLL(path)
+    P, I = C.c_void_p, C.c_int32
+    L.rcc_abi_version.restype = C.c_int
+    L.rcc_status_string.restype = C.c_char_p
+    L.rcc_status_string.argtypes = [C.c_int]
+    L.rcc_last_device_error.restype = C.c_char_p
+    L.rcc_last_device_error.argtypes = [P]
+    L.rcc_default_config.argtypes = [C.POINTER(abi.rcc_config)]
+    L.rcc_default_config.restype = None
+    L.rcc_create.argtypes = [C.POINTER(abi.rcc_config), C.POINTER(P)]
+    L.rcc_destroy.argtypes = [P]
+    L.rcc_destroy.restype = None
+    L.rcc_detect_batch.argtypes = [P, P, I, I, P, C.POINTER(I), P, P]
+    L.rcc_solve_pnp_batch.argtypes = [P, P, P, P, I, P, P, I, P, P, P, P, P]
+    L.rcc_rodrigues_v2m_batch.argtypes = [P, P, I, P]
+    L.rcc_rodrigues_m2v_batch.argtypes = [P, P, I, P]
+    L.rcc_stage_ingest.argtypes = [P, P, I, P, P]
+    L.rcc_stage_threshold_corner.argtypes = [P, P, I, P, P, P, P]
+    L.rcc_stage_targets.argtypes = [P, P, P, P, P, I, P, C.POINTER(I), P, P]
+    L.rcc_set_dense_variant.argtypes = [P, C.c_int]
+    L.rcc_set_ingest_variant.argtypes = [P, C.c_int]
+    L.rcc_last_timings.argtypes = [P, P, I]
+    L.rcc_time_dense.argtypes = [P, P, I, P, P, P, I, C.POINTER(C.c_float)]
+    L.rcc_time_ingest.argtypes = [P, P, I, P, I, C.POINTER(C.c_float)]
+    L.rcc_synth_render_batch.argtypes = [P, C.POINTER(abi.rcc_synth_params), P, I, I, P, P]
+    L.rcc_debug_fetch_lists.argtypes = [P, I, P, P, P, P, P]
+    L.rcc_debug_fetch_images.argtypes = [P, I, P, P, P, P]
+    for name in ("rcc_create", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
+                 "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_stage_targets",
+                 "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_last_timings", "rcc_time_dense",
+                 "rcc_time_ingest", "rcc_synth_render_batch", "rcc_debug_fetch_lists", "rcc_debug_fetch_images"):
+        getattr(L, name).restype = C.c_int
+    if L.rcc_abi_version() != abi.RCC_ABI_VERSION:
+        raise RuntimeError("librcc_hip.so ABI version %d != %d" % (L.rcc_abi_version(), abi.RCC_ABI_VERSION))
+    _lib = L
+    return L
+
+
+# every symbol include/rcc.h declares (the CPU-side test checks the library exports them all)
+EXPORTED_SYMBOLS = (
+    "rcc_default_config", "rcc_create", "rcc_destroy", "rcc_status_string", "rcc_last_device_error",
+    "rcc_abi_version", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
+    "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_set_dense_variant",
+    "rcc_set_ingest_variant", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
+    "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch",
+)
+
+
+def status_string(status):
+    try:
+        return load_library().rcc_status_string(int(status)).decode()
+    except Exception:  # library absent: still give a readable message
+        return {0: "ok", -1: "invalid argument", -2: "unsupported configuration", -3: "HIP device error",
+                -4: "batch exceeds handle capacity", -5: "out of memory"}.get(int(status), "unknown status")
+
+
+def default_config():
+    cfg = abi.rcc_config()
+    load_library().rcc_default_config(C.byref(cfg))
+    return cfg
+
+
+def _ptr(x):
+    """Raw address of a numpy array, a torch tensor (host or device), an int, or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if isinstance(x, np.ndarray):
+        return C.c_void_p(x.ctypes.data)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError("cannot take the address of %r" % type(x))
+
+
+def _is_device(x):
+    return hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+CAND_DT = np.dtype([("x", np.int16), ("y", np.int16), ("score", np.int32)])
+
+
+class Detector:
+    """One handle = one GPU + one configuration (not thread-safe; one per thread)."""
+
+    def __init__(self, cfg):
+        self._L = load_library()
+        self.cfg = cfg
+        h = C.c_void_p()
+        st = self._L.rcc_create(C.byref(cfg), C.byref(h))
+        if st != abi.RCC_OK:
+            raise RccError(st, "rcc_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rcc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, st, where):
+        if st != abi.RCC_OK:
+            raise RccError(st, where, self._L.rcc_last_device_error(self._h).decode())
+
+    # ---- the hot path -------------------------------------------------------------------------
+    def detect(self, frames, nframes=None, want_corners=True, stream=None):
+        """frames: numpy uint8 array (host) or torch uint8 tensor (host or device), nframes images
+        frame_bytes apart.  Returns (detections, frame_corners): ctypes arrays of rcc_detection
+        (length ndet) and rcc_frame_corners (length nframes, or None)."""
+        if nframes is None:
+            nframes = int(frames.shape[0])
+        mem = abi.RCC_MEM_DEVICE if _is_device(frames) else abi.RCC_MEM_HOST
+        if mem == abi.RCC_MEM_HOST and isinstance(frames, np.ndarray):
+            frames = np.ascontiguousarray(frames)
+        det = (abi.rcc_detection * max(nframes * self.cfg.max_targets, 1))()
+        fc = (abi.rcc_frame_corners * max(nframes, 1))() if want_corners else None
+        ndet = C.c_int32(0)
+        st = self._L.rcc_detect_batch(self._h, _ptr(frames), nframes, mem, det, C.byref(ndet),
+                                      fc if fc is not None else None, _ptr(stream))
+        self._chk(st, "rcc_detect_batch")
+        return det[:ndet.value], (fc[:nframes] if fc is not None else None)
+
+    def solve_pnp(self, obj_pts, img_pts, K=None, D=None, dist_model=None):
+        """Batched cv::solvePnP(obj, img, K, D, rvec, tvec, false, CV_ITERATIVE)
+        (camera_pose.cpp:163).  obj_pts/img_pts: lists of (n_i,3)/(n_i,2) arrays, or single arrays
+        of shape (T,n,3)/(T,n,2).  Returns rvec (T,3), tvec (T,3), rms (T,), status (T,), iters (T,)."""
+        objs = [np.asarray(o, np.float64).reshape(-1, 3) for o in obj_pts]
+        imgs = [np.asarray(i, np.float64).reshape(-1, 2) for i in img_pts]
+        T = len(objs)
+        npts = np.array([len(o) for o in objs], np.int32)
+        obj = np.ascontiguousarray(np.concatenate(objs, 0)) if T else np.zeros((0, 3))
+        img = np.ascontiguousarray(np.concatenate(imgs, 0)) if T else np.zeros((0, 2))
+        rvec = np.zeros((T, 3)); tvec = np.zeros((T, 3)); rms = np.zeros(T)
+        status = np.zeros(T, np.int32); iters = np.zeros(T, np.int32)
+        Kp = np.ascontiguousarray(K, np.float64).reshape(9) if K is not None else None
+        Dp = None
+        if D is not None:
+            Dp = np.zeros(8)
+            Dp[:len(D)] = np.asarray(D, np.float64).ravel()[:8]
+        model = self.cfg.dist_model if dist_model is None else dist_model
+        st = self._L.rcc_solve_pnp_batch(self._h, _ptr(obj), _ptr(img), _ptr(npts), T, _ptr(Kp), _ptr(Dp), model,
+                                         _ptr(rvec), _ptr(tvec), _ptr(rms), _ptr(status), _ptr(iters))
+        self._chk(st, "rcc_solve_pnp_batch")
+        return rvec, tvec, rms, status, iters
+
+    def rodrigues(self, x):
+        """cv::Rodrigues both ways (camera_pose.cpp:93,116,164): (n,3) -> (n,3,3) or (n,3,3) -> (n,3)."""
+        x = np.ascontiguousarray(x, np.float64)
+        if x.ndim == 2 and x.shape[1] == 3:
+            out = np.zeros((len(x), 3, 3))
+            self._chk(self._L.rcc_rodrigues_v2m_batch(self._h, _ptr(x), len(x), _ptr(out)), "rcc_rodrigues_v2m_batch")
+            return out
+        x = x.reshape(-1, 9)
+        out = np.zeros((len(x), 3))
+        self._chk(self._L.rcc_rodrigues_m2v_batch(self._h, _ptr(x), len(x), _ptr(out)), "rcc_rodrigues_m2v_batch")
+        return out
+
+    # ---- stage-level (device pointers) -----------------------------------------------------------
+    def stage_ingest(self, d_frames, nframes, d_grey, stream=None):
+        self._chk(self._L.rcc_stage_ingest(self._h, _ptr(d_frames), nframes, _ptr(d_grey), _ptr(stream)), "rcc_stage_ingest")
+
+    def stage_threshold_corner(self, d_grey, nframes, d_bin, d_cand, d_count, stream=None):
+        self._chk(self._L.rcc_stage_threshold_corner(self._h, _ptr(d_grey), nframes, _ptr(d_bin), _ptr(d_cand),
+                                                     _ptr(d_count), _ptr(stream)), "rcc_stage_threshold_corner")
+
+    def stage_targets(self, d_grey, d_bin, d_cand, d_count, nframes, want_corners=True, stream=None):
+        det = (abi.rcc_detection * max(nframes * self.cfg.max_targets, 1))()
+        fc = (abi.rcc_frame_corners * max(nframes, 1))() if want_corners else None
+        ndet = C.c_int32(0)
+        st = self._L.rcc_stage_targets(self._h, _ptr(d_grey), _ptr(d_bin), _ptr(d_cand), _ptr(d_count), nframes,
+                                       det, C.byref(ndet), fc if fc is not None else None, _ptr(stream))
+        self._chk(st, "rcc_stage_targets")
+        return det[:ndet.value], (fc[:nframes] if fc is not None else None)
+
+    def set_dense_variant(self, v):
+        return self._L.rcc_set_dense_variant(self._h, int(v))
+
+    def set_ingest_variant(self, v):
+        return self._L.rcc_set_ingest_variant(self._h, int(v))
+
+    def last_timings(self):
+        ms = (C.c_float * 5)()
+        self._L.rcc_last_timings(self._h, ms, 5)
+        return dict(zip(("ingest", "dense", "list_subpix_grid", "pnp", "d2h"), [float(v) for v in ms]))
+
+    def time_dense(self, d_grey, nframes, d_bin, d_cand, d_count, reps):
+        ms = C.c_float(0)
+        self._chk(self._L.rcc_time_dense(self._h, _ptr(d_grey), nframes, _ptr(d_bin), _ptr(d_cand), _ptr(d_count),
+                                         reps, C.byref(ms)), "rcc_time_dense")
+        return float(ms.value)
+
+    def time_ingest(self, d_frames, nframes, d_grey, reps):
+        ms = C.c_float(0)
+        self._chk(self._L.rcc_time_ingest(self._h, _ptr(d_frames), nframes, _ptr(d_grey), reps, C.byref(ms)), "rcc_time_ingest")
+        return float(ms.value)
+
+    def synth_render(self, sp, poses, d_frames, first_index=0, stream=None):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 6)
+        self._chk(self._L.rcc_synth_render_batch(self._h, C.byref(sp), _ptr(poses), len(poses), first_index,
+                                                 _ptr(d_frames), _ptr(stream)), "rcc_synth_render_batch")
+
+    # ---- test taps ---------------------------------------------------------------------------------
+    def fetch_lists(self, nframes):
+        pre = np.zeros((nframes, 256), CAND_DT); kept = np.zeros((nframes, 256), CAND_DT)
+        npre = np.zeros(nframes, np.int32)
+        pre_xy = np.zeros((nframes, 256, 2)); kept_xy = np.zeros((nframes, 256, 2))
+        self._chk(self._L.rcc_debug_fetch_lists(self._h, nframes, _ptr(pre), _ptr(npre), _ptr(pre_xy), _ptr(kept), _ptr(kept_xy)),
+                  "rcc_debug_fetch_lists")
+        return dict(pre=pre, npre=npre, pre_xy=pre_xy, kept=kept, kept_xy=kept_xy)
+
+    def fetch_images(self, nframes):
+        w, h = self.cfg.width, self.cfg.height
+        grey = np.zeros((nframes, h, w), np.uint8); binm = np.zeros((nframes, h, w), np.uint8)
+        cand = np.zeros((nframes, self.cfg.max_candidates), CAND_DT)
+        cnt = np.zeros(nframes, np.int32)
+        self._chk(self._L.rcc_debug_fetch_images(self._h, nframes, _ptr(grey), _ptr(binm), _ptr(cand), _ptr(cnt)),
+                  "rcc_debug_fetch_images")
+        return dict(grey=grey, bin=binm, cand=cand, cand_count=cnt)
+
+
+def detections_to_dicts(dets):
+    """Plain-python view of rcc_detection records with the field names the reference reads
+    (corner_detections.cpp:48-54): id, size, pixel_corners_x/y (bl,br,tr,tl) + pose."""
+    out = []
+    for d in dets:
+        out.append(dict(frame=d.frame, id=d.id, size=d.size,
+                        pixel_corners_x=[d.corners[k][0] for k in range(4)],
+                        pixel_corners_y=[d.corners[k][1] for k in range(4)],
+                        rvec=list(d.rvec), tvec=list(d.tvec), rms=d.rms,
+                        pnp_status=d.pnp_status, pnp_iters=d.pnp_iters, ncorners=d.ncorners, hamming=d.hamming))
+    return out

@@ -1,0 +1,221 @@
+// k_dense.hip -- the "threshold + corner pass": stages a3 (apriltag tile threshold) and a4.1
+// (integer Harris response, 3x3 maximum selection, wave-ballot compaction), fused: one read of the
+// grey image, one write of the threshold map, a short candidate list.
+//
+// Stands in for the per-pixel passes of the external detector (apriltag threshold(); SURVEY.md
+// section 3.1) whose output the reference consumes at corner_detections.cpp:41-56.  Definitions:
+// SURVEY appendix B.3 (threshold) and DESIGN.md section 3 (integer Harris, k = 1/16).
+//
+// Algorithmic HBM bytes: 2 B/px (1 read + 1 written) = 4.147 MB per 1080p frame.
+//
+// Variant 0 (this kernel, k_dense_lds): any geometry.  One 256-thread block per 64x32 pixel
+// block of 4x4 threshold tiles (the last block of a row/column absorbs the <=3 ragged pixels);
+// the grey region with a 4-pixel halo is staged in LDS once and every stencil stage reads LDS.
+#include "rcc_internal.h"
+
+#define BW 64
+#define BH 32
+#define GR_W 80            // grey region row pitch (>= BW + 3 + 11)
+#define GR_H (BH + 3 + 11) // 46: 4-px halo each side + 3 ragged px of a last tile seen as halo
+#define PR_W (BW + 3 + 6)  // products region width  (73)
+#define PR_H (BH + 3 + 6)  // 41
+#define HS_W (BW + 3 + 2)  // hsum / R region width (69)
+#define TL_W 18            // threshold tiles incl. halo
+#define TL_H 10
+
+__global__ __launch_bounds__(256) void k_dense_lds(const uint8_t* __restrict__ grey, int w, int h,
+                                                   int nbx, int nby, int min_contrast, int hthresh,
+                                                   int margin, int cap, uint8_t* __restrict__ bin,
+                                                   rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count)
+{
+  __shared__ uint8_t sg[GR_H][GR_W];
+  __shared__ int16_t spxx[PR_H][PR_W], spxy[PR_H][PR_W], spyy[PR_H][PR_W];
+  __shared__ int16_t shxx[PR_H][HS_W], shxy[PR_H][HS_W], shyy[PR_H][HS_W];
+  __shared__ int32_t sR[BH + 3 + 2][HS_W];
+  __shared__ uint8_t stmin[TL_H][TL_W], stmax[TL_H][TL_W];
+  __shared__ uint8_t sdmin[TL_H][TL_W], sdmax[TL_H][TL_W];
+
+  const int tid = threadIdx.x;
+  const int f = blockIdx.z;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  int tw = w >> 2, th = h >> 2;
+  if (tw < 1) tw = 1;
+  if (th < 1) th = 1;
+  const int x0 = bx * BW, y0 = by * BH;
+  const int x1 = (bx == nbx - 1) ? w : x0 + BW;   // exclusive
+  const int y1 = (by == nby - 1) ? h : y0 + BH;
+  const int bw = x1 - x0, bh = y1 - y0;           // <= 67, <= 35
+  const uint8_t* g = grey + (size_t)f * w * h;
+  uint8_t* bo = bin + (size_t)f * w * h;
+
+  // ---- stage 0: grey region [x0-4, x1+7) x [y0-4, y1+7), coordinates clamped to the image
+  // (+3: an extended last tile can be the right/bottom halo tile of the block before it)
+  const int rw = bw + 11, rh = bh + 11;
+  for (int i = tid; i < rw * rh; i += 256) {
+    int ry = i / rw, rx = i - ry * rw;
+    int gx = min(max(x0 - 4 + rx, 0), w - 1), gy = min(max(y0 - 4 + ry, 0), h - 1);
+    sg[ry][rx] = g[(size_t)gy * w + gx];
+  }
+  __syncthreads();
+
+  // ---- stage 1: threshold-tile min/max for tiles [tx0-1, ...] (halo of one tile)
+  const int tx0 = x0 >> 2, ty0 = y0 >> 2;
+  const int ntx = ((bx == nbx - 1) ? tw - tx0 : BW / 4), nty = ((by == nby - 1) ? th - ty0 : BH / 4);
+  for (int i = tid; i < TL_W * TL_H; i += 256) {
+    int j = i / TL_W, k = i - j * TL_W;
+    int tx = tx0 - 1 + k, ty = ty0 - 1 + j;
+    int mn = 255, mx = 0;
+    if (k < ntx + 2 && j < nty + 2 && tx >= 0 && tx < tw && ty >= 0 && ty < th) {
+      int px0 = tx * 4, px1 = (tx == tw - 1) ? w : px0 + 4;
+      int py0 = ty * 4, py1 = (ty == th - 1) ? h : py0 + 4;
+      for (int yy = py0; yy < py1; ++yy)
+        for (int xx = px0; xx < px1; ++xx) {
+          int v = sg[yy - (y0 - 4)][xx - (x0 - 4)];
+          mn = min(mn, v);
+          mx = max(mx, v);
+        }
+    }
+    stmin[j][k] = (uint8_t)mn;
+    stmax[j][k] = (uint8_t)mx;
+  }
+  __syncthreads();
+  for (int i = tid; i < TL_W * TL_H; i += 256) {
+    int j = i / TL_W, k = i - j * TL_W;
+    int mn = 255, mx = 0;
+    if (j >= 1 && j <= nty && k >= 1 && k <= ntx) {
+      for (int dj = -1; dj <= 1; ++dj)
+        for (int dk = -1; dk <= 1; ++dk) {
+          mn = min(mn, (int)stmin[j + dj][k + dk]);
+          mx = max(mx, (int)stmax[j + dj][k + dk]);
+        }
+    }
+    sdmin[j][k] = (uint8_t)mn;
+    sdmax[j][k] = (uint8_t)mx;
+  }
+
+  // ---- stage 2: gradients and products on [x0-3, x1+3) x [y0-3, y1+3)
+  const int pw = bw + 6, ph = bh + 6;
+  for (int i = tid; i < pw * ph; i += 256) {
+    int py = i / pw, px = i - py * pw;
+    const int ry = py + 1, rx = px + 1;   // region coordinates of this pixel
+    int a00 = sg[ry - 1][rx - 1], a01 = sg[ry - 1][rx], a02 = sg[ry - 1][rx + 1];
+    int a10 = sg[ry][rx - 1], a12 = sg[ry][rx + 1];
+    int a20 = sg[ry + 1][rx - 1], a21 = sg[ry + 1][rx], a22 = sg[ry + 1][rx + 1];
+    int sx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
+    int sy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+    int gx = sx >> 3, gy = sy >> 3;
+    spxx[py][px] = (int16_t)((gx * gx) >> 4);
+    spxy[py][px] = (int16_t)((gx * gy) >> 4);
+    spyy[py][px] = (int16_t)((gy * gy) >> 4);
+  }
+  __syncthreads();
+
+  // ---- stage 3: threshold map for the block's pixels
+  for (int i = tid; i < bw * bh; i += 256) {
+    int py = i / bw, px = i - py * bw;
+    int x = x0 + px, y = y0 + py;
+    int k = min(x >> 2, tw - 1) - tx0 + 1, j = min(y >> 2, th - 1) - ty0 + 1;
+    int mn = sdmin[j][k], mx = sdmax[j][k];
+    int v = sg[py + 4][px + 4];
+    uint8_t o = (mx - mn < min_contrast) ? (uint8_t)127 : ((v > mn + (mx - mn) / 2) ? (uint8_t)255 : (uint8_t)0);
+    bo[(size_t)y * w + x] = o;
+  }
+
+  // ---- stage 4: horizontal 5-sums on columns [x0-1, x1+1), rows [y0-3, y1+3)
+  const int hw = bw + 2;
+  for (int i = tid; i < hw * ph; i += 256) {
+    int py = i / hw, hx = i - py * hw;
+    int a = 0, b = 0, c = 0;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) { a += spxx[py][hx + d]; b += spxy[py][hx + d]; c += spyy[py][hx + d]; }
+    shxx[py][hx] = (int16_t)a;
+    shxy[py][hx] = (int16_t)b;
+    shyy[py][hx] = (int16_t)c;
+  }
+  __syncthreads();
+
+  // ---- stage 5: vertical 5-sums -> response on [x0-1, x1+1) x [y0-1, y1+1)
+  const int rh2 = bh + 2;
+  for (int i = tid; i < hw * rh2; i += 256) {
+    int ry = i / hw, hx = i - ry * hw;
+    int x = x0 - 1 + hx, y = y0 - 1 + ry;
+    int32_t r = INT32_MIN;
+    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+      int A = 0, B = 0, C = 0;
+#pragma unroll
+      for (int d = 0; d < 5; ++d) { A += shxx[ry + d][hx]; B += shxy[ry + d][hx]; C += shyy[ry + d][hx]; }
+      uint32_t tr = (uint32_t)(A + C);
+      r = A * C - B * B - (int32_t)((tr * tr) >> 4);
+    }
+    sR[ry][hx] = r;
+  }
+  __syncthreads();
+
+  // ---- stage 6: 3x3 maximum selection + wave-ballot compaction
+  if (margin < 4) margin = 4;
+  const int npx = bw * bh;
+  for (int base = 0; base < npx; base += 256) {
+    int i = base + tid;
+    bool is = false;
+    int x = 0, y = 0;
+    int32_t r = 0;
+    if (i < npx) {
+      int py = i / bw, px = i - py * bw;
+      x = x0 + px; y = y0 + py;
+      r = sR[py + 1][px + 1];
+      if (r >= hthresh && x >= margin && x < w - margin && y >= margin && y < h - margin) {
+        is = r > sR[py][px] && r > sR[py][px + 1] && r > sR[py][px + 2] && r > sR[py + 1][px] &&
+             r >= sR[py + 1][px + 2] && r >= sR[py + 2][px] && r >= sR[py + 2][px + 1] && r >= sR[py + 2][px + 2];
+      }
+    }
+    unsigned long long m = __ballot(is);
+    if (m) {
+      const int lane = tid & 63;
+      int basei = 0;
+      if (lane == 0) basei = atomicAdd(&cand_count[f], __popcll(m));
+      basei = __shfl(basei, 0);
+      if (is) {
+        int idx = basei + __popcll(m & ((1ull << lane) - 1ull));
+        if (idx < cap) {
+          rcc_cand e;
+          e.x = (int16_t)x; e.y = (int16_t)y; e.score = r;
+          cand[(size_t)f * cap + idx] = e;
+        }
+      }
+    }
+  }
+}
+
+hipError_t rcc_launch_dense_fast(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
+                                 rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
+bool rcc_dense_fast_supported(const rcc_handle* h);
+
+hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
+                            rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s)
+{
+  const rcc_config& c = h->cfg;
+  if (nframes <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(d_cand_count, 0, sizeof(int32_t) * (size_t)nframes, s);
+  if (e != hipSuccess) return e;
+  int variant = h->dense_variant;
+  if (variant < 0) variant = rcc_dense_fast_supported(h) ? 1 : 0;
+  if (variant == 1 && rcc_dense_fast_supported(h))
+    return rcc_launch_dense_fast(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s);
+  const int w = c.width, ht = c.height;
+  int tw = w >> 2, th = ht >> 2;
+  if (tw < 1) tw = 1;
+  if (th < 1) th = 1;
+  const int nbx = (tw * 4 + BW - 1) / BW, nby = (th * 4 + BH - 1) / BH;
+  dim3 grid(nbx, nby, nframes);
+  hipLaunchKernelGGL(k_dense_lds, grid, dim3(256), 0, s, d_grey, w, ht, nbx, nby, c.thr_min_contrast,
+                     c.harris_thresh, c.cand_margin, c.max_candidates, d_bin, d_cand, d_cand_count);
+  return hipGetLastError();
+}
+
+// The row-marching fast kernel lands in k_dense_fast.hip; until it exists this reports "not
+// supported" so the generic kernel serves every geometry.
+__attribute__((weak)) bool rcc_dense_fast_supported(const rcc_handle*) { return false; }
+__attribute__((weak)) hipError_t rcc_launch_dense_fast(rcc_handle*, const uint8_t*, int, uint8_t*, rcc_cand*, int32_t*, hipStream_t)
+{
+  return hipErrorNotSupported;
+}

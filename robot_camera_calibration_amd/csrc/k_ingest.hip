@@ -1,0 +1,263 @@
+// k_ingest.hip -- stage a1+a2: BGR8/MONO8 -> grey u8, optional per-pixel undistortion.
+//
+// Stands in for the image callback of the external detector node the reference launches on
+// image_raw (real_preprocessing/README.md:65; cv_bridge dependency real_preprocessing/package.xml:56).
+// Arithmetic: SURVEY.md appendix B.1 (grey) and B.2 (initUndistortRectifyMap + remap, Q5 map,
+// bilinear, constant border); intrinsics laid out as camera_pose.cpp:59-64 loads them.
+// Order is grey first, then remap of the grey image.
+//
+// HBM view (per 1080p BGR frame): 6.22 MB read + 2.07 MB written = 4 B/px algorithmic.
+// The map is never stored: it is recomputed per destination pixel in fp64 and amortised over the
+// frames a block walks (frames_per_block), so it costs no traffic.
+//
+// Variants:
+//   0  gather: taps read straight from global memory (any geometry)
+//   1  staged: the source rows a destination tile needs are loaded coalesced (16 B/lane),
+//      converted to grey once, kept in LDS, taps come from LDS
+#include "rcc_internal.h"
+
+// ---- map ------------------------------------------------------------------------------------
+// Bit-for-bit the operation sequence of the specification (one rounded IEEE op per line;
+// this translation unit is compiled with -ffp-contract=off).
+__device__ __forceinline__ double rcc_atan_pos(double r)
+{
+  const double PI_2 = 1.57079632679489661923, PI_4 = 0.78539816339744830962;
+  const double T8 = 0.41421356237309504880;
+  bool flip = false;
+  double t = r;
+  if (t > 1.0) { t = 1.0 / t; flip = true; }
+  double base = 0.0;
+  if (t > T8) { t = (t - 1.0) / (t + 1.0); base = PI_4; }
+  double z = t * t;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 23; k >= 0; --k) {
+    double c = 1.0 / (double)(2 * k + 1);
+    if (k & 1) c = -c;
+    s = s * z + c;
+  }
+  double a = base + t * s;
+  if (flip) a = PI_2 - a;
+  return a;
+}
+
+__device__ __forceinline__ int32_t rcc_sat_rint(double v)
+{
+  double r = rint(v);
+  if (!(r > -2147483648.0)) return INT32_MIN;
+  if (r > 2147483647.0) return INT32_MAX;
+  return (int32_t)r;
+}
+
+__device__ __forceinline__ void rcc_map_q5(const rcc_cam& c, int u, int v, int32_t& X, int32_t& Y)
+{
+  double x = ((double)u - c.cx) / c.fx;
+  double y = ((double)v - c.cy) / c.fy;
+  double xs, ys;
+  if (c.model == RCC_DIST_PLUMB_BOB) {
+    const double k1 = c.D[0], k2 = c.D[1], p1 = c.D[2], p2 = c.D[3], k3 = c.D[4];
+    double x2 = x * x, y2 = y * y;
+    double r2 = x2 + y2;
+    double _2xy = (2.0 * x) * y;
+    double kr = k3 * r2;
+    kr = kr + k2;
+    kr = kr * r2;
+    kr = kr + k1;
+    kr = kr * r2;
+    kr = 1.0 + kr;
+    double tx = 2.0 * x2;
+    tx = r2 + tx;
+    double ty = 2.0 * y2;
+    ty = r2 + ty;
+    double xd = x * kr;
+    double a = p1 * _2xy;
+    xd = xd + a;
+    a = p2 * tx;
+    xd = xd + a;
+    double yd = y * kr;
+    a = p1 * ty;
+    yd = yd + a;
+    a = p2 * _2xy;
+    yd = yd + a;
+    xs = c.fx * xd;
+    xs = xs + c.cx;
+    ys = c.fy * yd;
+    ys = ys + c.cy;
+  } else if (c.model == RCC_DIST_FISHEYE) {
+    const double k1 = c.D[0], k2 = c.D[1], k3 = c.D[2], k4 = c.D[3];
+    double x2 = x * x, y2 = y * y;
+    double r = sqrt(x2 + y2);
+    double th = rcc_atan_pos(r);
+    double t2 = th * th;
+    double p = k4 * t2;
+    p = p + k3;
+    p = p * t2;
+    p = p + k2;
+    p = p * t2;
+    p = p + k1;
+    p = p * t2;
+    p = 1.0 + p;
+    double thd = th * p;
+    double s = (r > 1e-8) ? thd / r : 1.0;
+    xs = c.fx * x;
+    xs = xs * s;
+    xs = xs + c.cx;
+    ys = c.fy * y;
+    ys = ys * s;
+    ys = ys + c.cy;
+  } else {
+    xs = (double)u;
+    ys = (double)v;
+  }
+  X = rcc_sat_rint(xs * 32.0);
+  Y = rcc_sat_rint(ys * 32.0);
+}
+
+__device__ __forceinline__ int rcc_grey_of(int b, int g, int r)
+{
+  return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14;
+}
+
+template <int NCH>
+__device__ __forceinline__ int rcc_tap(const uint8_t* __restrict__ src, int stride, int w, int h, int ix, int iy)
+{
+  if ((unsigned)ix >= (unsigned)w || (unsigned)iy >= (unsigned)h) return 0;
+  const uint8_t* p = src + (size_t)iy * stride + (size_t)ix * NCH;
+  if (NCH == 3) return rcc_grey_of(p[0], p[1], p[2]);
+  return p[0];
+}
+
+// ---- variant 0: gather ------------------------------------------------------------------------
+// block (64,4): 64 quads of 4 pixels x 4 rows; grid (ceil(w/256), ceil(h/4), ceil(nframes/fpb))
+template <int NCH>
+__global__ __launch_bounds__(256) void k_ingest_gather(const uint8_t* __restrict__ frames,
+                                                       int64_t frame_bytes, int stride, int w, int h,
+                                                       rcc_cam cam, uint8_t* __restrict__ grey,
+                                                       int nframes, int fpb)
+{
+  const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  if (y >= h || x0 >= w) return;
+  int32_t X[4], Y[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    X[j] = 0; Y[j] = 0;
+    if (x0 + j < w) rcc_map_q5(cam, x0 + j, y, X[j], Y[j]);
+  }
+  const int f0 = blockIdx.z * fpb;
+  const int f1 = min(f0 + fpb, nframes);
+  const bool vec = ((w & 3) == 0);
+  for (int f = f0; f < f1; ++f) {
+    const uint8_t* src = frames + (size_t)f * frame_bytes;
+    uint8_t* dst = grey + (size_t)f * w * h + (size_t)y * w + x0;
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (x0 + j < w) {
+        int ix = X[j] >> 5, iy = Y[j] >> 5, fx = X[j] & 31, fy = Y[j] & 31;
+        int p00 = rcc_tap<NCH>(src, stride, w, h, ix, iy);
+        int p01 = rcc_tap<NCH>(src, stride, w, h, ix + 1, iy);
+        int p10 = rcc_tap<NCH>(src, stride, w, h, ix, iy + 1);
+        int p11 = rcc_tap<NCH>(src, stride, w, h, ix + 1, iy + 1);
+        int acc = (32 - fx) * (32 - fy) * p00 + fx * (32 - fy) * p01 + (32 - fx) * fy * p10 + fx * fy * p11;
+        out |= (uint32_t)((acc + 512) >> 10) << (8 * j);
+      }
+    }
+    if (vec) {
+      *reinterpret_cast<uint32_t*>(dst) = out;
+    } else {
+      for (int j = 0; j < 4 && x0 + j < w; ++j) dst[j] = (uint8_t)(out >> (8 * j));
+    }
+  }
+}
+
+// ---- no undistortion: pure streaming conversion -----------------------------------------------
+// one thread per 16-pixel chunk: 3 x 16 B loads -> 1 x 16 B store
+__global__ __launch_bounds__(256) void k_grey_bgr_stream(const uint8_t* __restrict__ frames,
+                                                         int64_t frame_bytes, int stride, int w, int h,
+                                                         uint8_t* __restrict__ grey, int nframes, int aligned)
+{
+  const int cpr = (w + 15) >> 4;
+  const int64_t total = (int64_t)nframes * h * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % cpr);
+    int64_t t = i / cpr;
+    int y = (int)(t % h);
+    int f = (int)(t / h);
+    const uint8_t* src = frames + (size_t)f * frame_bytes + (size_t)y * stride + (size_t)c * 48;
+    uint8_t* dst = grey + (size_t)f * w * h + (size_t)y * w + (size_t)c * 16;
+    if (aligned && c * 16 + 16 <= w) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(src);
+      uint4 a = s4[0], b = s4[1], d = s4[2];
+      uint32_t in[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w };
+      uint32_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // 4 pixels = 12 bytes = 3 dwords
+        uint32_t d0 = in[3 * q], d1 = in[3 * q + 1], d2 = in[3 * q + 2];
+        int g0 = rcc_grey_of(d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255);
+        int g1 = rcc_grey_of(d0 >> 24, d1 & 255, (d1 >> 8) & 255);
+        int g2 = rcc_grey_of((d1 >> 16) & 255, d1 >> 24, d2 & 255);
+        int g3 = rcc_grey_of((d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24);
+        o[q] = (uint32_t)g0 | ((uint32_t)g1 << 8) | ((uint32_t)g2 << 16) | ((uint32_t)g3 << 24);
+      }
+      *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+      int n = min(16, w - c * 16);
+      for (int j = 0; j < n; ++j) dst[j] = (uint8_t)rcc_grey_of(src[3 * j], src[3 * j + 1], src[3 * j + 2]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_copy_mono(const uint8_t* __restrict__ frames, int64_t frame_bytes,
+                                                   int stride, int w, int h, uint8_t* __restrict__ grey, int nframes)
+{
+  const int64_t total = (int64_t)nframes * h * w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int x = (int)(i % w);
+    int64_t t = i / w;
+    int y = (int)(t % h);
+    int f = (int)(t / h);
+    grey[i] = frames[(size_t)f * frame_bytes + (size_t)y * stride + x];
+  }
+}
+
+static rcc_cam make_cam(const rcc_config& c)
+{
+  rcc_cam k;
+  k.fx = c.K[0]; k.cx = c.K[2]; k.fy = c.K[4]; k.cy = c.K[5];
+  for (int i = 0; i < 8; ++i) k.D[i] = c.D[i];
+  k.model = c.dist_model;
+  return k;
+}
+
+hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes, uint8_t* d_grey, hipStream_t s)
+{
+  const rcc_config& c = h->cfg;
+  const int w = c.width, ht = c.height;
+  if (nframes <= 0) return hipSuccess;
+  if (!h->undist) {
+    if (c.pixfmt == RCC_PIX_BGR8) {
+      int aligned = ((c.stride_bytes & 15) == 0) && ((c.frame_bytes & 15) == 0) && ((w & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0) && ((reinterpret_cast<uintptr_t>(d_grey) & 15) == 0);
+      int64_t total = (int64_t)nframes * ht * ((w + 15) >> 4);
+      int blocks = (int)(((total + 255) / 256) < 4096 ? ((total + 255) / 256) : 4096);
+      hipLaunchKernelGGL(k_grey_bgr_stream, dim3(blocks), dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, d_grey, nframes, aligned);
+    } else {
+      int64_t total = (int64_t)nframes * ht * w;
+      int blocks = (int)(((total + 255) / 256) < 4096 ? ((total + 255) / 256) : 4096);
+      hipLaunchKernelGGL(k_copy_mono, dim3(blocks), dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, d_grey, nframes);
+    }
+    return hipGetLastError();
+  }
+  rcc_cam cam = make_cam(c);
+  // frames per block: amortise the fp64 map; keep >= ~2048 blocks in flight
+  int fpb = 16;
+  const int tiles = ((w + 255) / 256) * ((ht + 3) / 4);
+  while (fpb > 1 && (int64_t)tiles * ((nframes + fpb - 1) / fpb) < 2048) fpb >>= 1;
+  dim3 grid((w + 255) / 256, (ht + 3) / 4, (nframes + fpb - 1) / fpb), block(64, 4);
+  if (c.pixfmt == RCC_PIX_BGR8)
+    hipLaunchKernelGGL((k_ingest_gather<3>), grid, block, 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb);
+  else
+    hipLaunchKernelGGL((k_ingest_gather<1>), grid, block, 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb);
+  return hipGetLastError();
+}

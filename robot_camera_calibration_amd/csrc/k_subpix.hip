@@ -1,0 +1,120 @@
+// k_subpix.hip -- stage a5: sub-pixel corner refinement, cornerSubPix form (SURVEY.md appendix
+// B.5), one 64-lane wavefront per corner.
+//
+// What the reference receives from this stage: pixel_corners_x/y[0..3] of each detection
+// (real_preprocessing/src/corner_detections.cpp:53-54, where it casts them to int).
+//
+// Numerics: binary64 throughout; the five window sums are accumulated
+// one bin per lane (bin = sample index mod 64, increasing index) and combined by an xor-butterfly
+// v += shfl_xor(v, off), off = 32..1.  IEEE addition is commutative, so every lane ends with the
+// same value and the result equals the specification's 64-bin pairwise tree bit for bit.
+// Compiled with -ffp-contract=off: every operation below is one rounded IEEE operation.
+#include "rcc_internal.h"
+
+#define SP_MAXW 7
+#define SP_MAXP (2 * SP_MAXW + 3)
+
+__device__ __forceinline__ double wave_tree_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+
+// grid (ceil(max_kept), nframes): block b handles candidate blockIdx.x of frame blockIdx.y
+__global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
+                                               const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
+                                               rcc_subpix_params sp, double* __restrict__ pre_xy)
+{
+  __shared__ double S[SP_MAXP * SP_MAXP];
+  const int f = blockIdx.y, q = blockIdx.x;
+  if (q >= npre[f]) return;
+  const int lane = threadIdx.x;
+  const uint8_t* g = grey + (size_t)f * w * h;
+  const rcc_cand c0 = pre[(size_t)f * RCC_MAX_KEPT + q];
+  const int win = sp.win;
+  const int ww = 2 * win + 1, pw = 2 * win + 3;
+  const double x0 = (double)c0.x, y0 = (double)c0.y;
+  double cx = x0, cy = y0;
+  int iter = 0;
+  bool bad = false;
+  double err = 0.0;
+  do {
+    double flx = floor(cx), fly = floor(cy);
+    int ix = (int)flx, iy = (int)fly;
+    if (ix - win - 1 < 0 || iy - win - 1 < 0 || ix + win + 2 > w - 1 || iy + win + 2 > h - 1) {
+      bad = true;
+      break;
+    }
+    double fx = cx - flx, fy = cy - fly;
+    double ofx = 1.0 - fx, ofy = 1.0 - fy;
+    double a00 = ofx * ofy, a01 = fx * ofy, a10 = ofx * fy, a11 = fx * fy;
+    __syncthreads();   // previous iteration's readers are done with S
+    for (int idx = lane; idx < pw * pw; idx += 64) {
+      int i = idx / pw, j = idx - i * pw;
+      const uint8_t* p = g + (size_t)(iy + i - win - 1) * w + (ix + j - win - 1);
+      double t0 = a00 * (double)p[0];
+      double t1 = a01 * (double)p[1];
+      double t2 = a10 * (double)p[w];
+      double t3 = a11 * (double)p[w + 1];
+      double s = t0 + t1;
+      s = s + t2;
+      s = s + t3;
+      S[idx] = s;
+    }
+    __syncthreads();
+    double a = 0.0, b = 0.0, c = 0.0, b1 = 0.0, b2 = 0.0;
+    for (int k = lane; k < ww * ww; k += 64) {
+      int i = k / ww, j = k - i * ww;
+      const double* spp = S + (i + 1) * pw + (j + 1);
+      double gx = spp[1] - spp[-1];
+      double gy = spp[pw] - spp[-pw];
+      double m = sp.m1[i] * sp.m1[j];
+      double gxx = (gx * gx) * m;
+      double gxy = (gx * gy) * m;
+      double gyy = (gy * gy) * m;
+      double px = (double)(j - win), py = (double)(i - win);
+      a = a + gxx;
+      b = b + gxy;
+      c = c + gyy;
+      double u1 = gxx * px, u2 = gxy * py;
+      b1 = b1 + (u1 + u2);
+      double v1 = gxy * px, v2 = gyy * py;
+      b2 = b2 + (v1 + v2);
+    }
+    a = wave_tree_sum(a);
+    b = wave_tree_sum(b);
+    c = wave_tree_sum(c);
+    double bb1 = wave_tree_sum(b1), bb2 = wave_tree_sum(b2);
+    double ac = a * c, bsq = b * b;
+    double det = ac - bsq;
+    if (fabs(det) <= 2.2204460492503131e-16 * 2.2204460492503131e-16) break;
+    double scale = 1.0 / det;
+    double cs = c * scale, bs = b * scale, as = a * scale;
+    double q1 = cs * bb1, q2 = bs * bb2;
+    double dx = q1 - q2;
+    double q3 = as * bb2, q4 = bs * bb1;
+    double dy = q3 - q4;
+    double nx = cx + dx, ny = cy + dy;
+    double ex = nx - cx, ey = ny - cy;
+    double e1 = ex * ex, e2 = ey * ey;
+    err = e1 + e2;
+    cx = nx; cy = ny;
+    if (cx < 0.0 || cx >= (double)w || cy < 0.0 || cy >= (double)h) break;
+  } while (++iter < sp.max_iter && err > sp.eps2);
+  if (bad || fabs(cx - x0) > (double)win || fabs(cy - y0) > (double)win) { cx = x0; cy = y0; }
+  if (lane == 0) {
+    pre_xy[((size_t)f * RCC_MAX_KEPT + q) * 2] = cx;
+    pre_xy[((size_t)f * RCC_MAX_KEPT + q) * 2 + 1] = cy;
+  }
+}
+
+hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s)
+{
+  const rcc_config& c = h->cfg;
+  if (nframes <= 0) return hipSuccess;
+  int max_kept = c.max_kept < RCC_MAX_KEPT ? c.max_kept : RCC_MAX_KEPT;
+  hipLaunchKernelGGL(k_subpix, dim3(max_kept, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
+                     h->d_pre, h->d_npre, h->sp, h->d_pre_xy);
+  return hipGetLastError();
+}

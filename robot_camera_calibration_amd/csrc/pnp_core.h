@@ -1,0 +1,575 @@
+// pnp_core.h -- stage a7/a8 arithmetic: planar PnP in the solvePnP(ITERATIVE) form, and Rodrigues.
+//
+// Drop-in target: cv::solvePnP(obj_pts, img_pts, kcam_matrix, kdistCoeffs, rvec, tvec, false,
+// CV_ITERATIVE) at real_preprocessing/src/camera_pose.cpp:163 (points bl,br,tr,tl :152-155, object
+// points (+-size/2, +-size/2, 0) :158-161, K/D as loaded at :59-64) and cv::Rodrigues at :93,:116,
+// :164 and opt_visualization.cpp:36.  Algorithm: SURVEY.md appendix A.2-A.8 (OpenCV 3.4.x as
+// published; not present in this image).
+//
+// Written as per-thread code with NO per-point storage: normal equations are accumulated point by
+// point (JtJ 6x6, Jte 6; for the homography refinement 8x8, 8), normalised points are recomputed
+// where needed.  One lane per target (k_pnp.hip) runs this as is; the wave-per-target kernel
+// shares the small dense algebra and spreads the per-point work over lanes.
+//
+// RCC_HD lets a host build of the same functions be exercised on the CPU (tests/test_pnp_core_host).
+#pragma once
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+
+#ifndef RCC_HD
+#ifdef __HIPCC__
+#define RCC_HD __host__ __device__
+#else
+#define RCC_HD
+#endif
+#endif
+
+#ifndef RCC_DIST_PLUMB_BOB
+#define RCC_DIST_NONE 0
+#define RCC_DIST_PLUMB_BOB 1
+#define RCC_DIST_FISHEYE 2
+#endif
+
+namespace rccpnp {
+
+enum { PNP_OK = 0, PNP_TOO_FEW = 1, PNP_NONPLANAR = 2, PNP_DEGENERATE = 3 };
+
+struct Cam {
+  double fx, fy, cx, cy;
+  double k[5];  // k1,k2,p1,p2,k3 (zero when the model is NONE)
+};
+
+// ---- symmetric eigen-decomposition (cyclic Jacobi), n <= 9; V rows = eigenvectors, w descending
+RCC_HD inline void jacobi_eigen_sym(int n, double* A, double* w, double* V)
+{
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int p = 0; p < n; ++p) {
+      diag += A[p * n + p] * A[p * n + p];
+      for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
+    }
+    if (off <= 1e-300 || off <= 1e-34 * diag) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        double apq = A[p * n + q];
+        if (apq == 0.0) continue;
+        double app = A[p * n + p], aqq = A[q * n + q];
+        double theta = (aqq - app) / (2.0 * apq);
+        double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+        if (theta < 0.0) t = -t;
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          double akp = A[k * n + p], akq = A[k * n + q];
+          A[k * n + p] = c * akp - s * akq;
+          A[k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          double apk = A[p * n + k], aqk = A[q * n + k];
+          A[p * n + k] = c * apk - s * aqk;
+          A[q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          double vpk = V[p * n + k], vqk = V[q * n + k];
+          V[p * n + k] = c * vpk - s * vqk;
+          V[q * n + k] = s * vpk + c * vqk;
+        }
+      }
+  }
+  for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+  for (int i = 0; i < n - 1; ++i) {
+    int m = i;
+    for (int j = i + 1; j < n; ++j) if (w[j] > w[m]) m = j;
+    if (m != i) {
+      double t = w[i]; w[i] = w[m]; w[m] = t;
+      for (int k = 0; k < n; ++k) { double u = V[i * n + k]; V[i * n + k] = V[m * n + k]; V[m * n + k] = u; }
+    }
+  }
+}
+
+// x = pinv(A) b, symmetric A (n <= 8), singular directions dropped as cv::solve(DECOMP_SVD) does.
+// T, V: n*n scratch; w: n scratch.
+RCC_HD inline void sym_solve(int n, const double* A, const double* b, double* x, double* T, double* V, double* w)
+{
+  for (int i = 0; i < n * n; ++i) T[i] = A[i];
+  jacobi_eigen_sym(n, T, w, V);
+  double thr = 0.0;
+  for (int i = 0; i < n; ++i) thr += fabs(w[i]);
+  thr *= 2.0 * DBL_EPSILON;
+  for (int k = 0; k < n; ++k) x[k] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (fabs(w[i]) <= thr) continue;
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) s += V[i * n + k] * b[k];
+    s /= w[i];
+    for (int k = 0; k < n; ++k) x[k] += s * V[i * n + k];
+  }
+}
+
+RCC_HD inline void mat3_mul(const double* A, const double* B, double* C)
+{
+  double T[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+  for (int i = 0; i < 9; ++i) C[i] = T[i];
+}
+
+RCC_HD inline double mat3_det(const double* M)
+{
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// ---- a8 Rodrigues (appendix A.6) ---------------------------------------------------------------
+RCC_HD inline void rodrigues_v2m(const double r[3], double R[9], double* J /* 27 or null */)
+{
+  double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+  if (theta < DBL_EPSILON) {
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (J) {
+      for (int i = 0; i < 27; ++i) J[i] = 0.0;
+      J[5] = J[15] = J[19] = -1.0;
+      J[7] = J[11] = J[21] = 1.0;
+    }
+    return;
+  }
+  double c = cos(theta), s = sin(theta), c1 = 1.0 - c, it = 1.0 / theta;
+  double rx = r[0] * it, ry = r[1] * it, rz = r[2] * it;
+  double rrt[9] = { rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz };
+  double rxm[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };
+  for (int k = 0; k < 9; ++k) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * rxm[k];
+  if (J) {
+    double drrt[27] = { rx + rx, ry, rz, ry, 0, 0, rz, 0, 0,
+                        0, rx, 0, rx, ry + ry, rz, 0, rz, 0,
+                        0, 0, rx, 0, 0, ry, rx, ry, rz + rz };
+    const double drxm[27] = { 0, 0, 0, 0, 0, -1, 0, 1, 0,
+                              0, 0, 1, 0, 0, 0, -1, 0, 0,
+                              0, -1, 0, 1, 0, 0, 0, 0, 0 };
+    for (int i = 0; i < 3; ++i) {
+      double ri = (i == 0) ? rx : (i == 1) ? ry : rz;
+      double a0 = -s * ri, a1 = (s - 2.0 * c1 * it) * ri, a2 = c1 * it, a3 = (c - s * it) * ri, a4 = s * it;
+      for (int k = 0; k < 9; ++k)
+        J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * rxm[k] + a4 * drxm[i * 9 + k];
+    }
+  }
+}
+
+RCC_HD inline void orthonormalise3(const double* M, double* Q)
+{
+  double MtM[9], w[3], V[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) MtM[i * 3 + j] = M[i] * M[j] + M[3 + i] * M[3 + j] + M[6 + i] * M[6 + j];
+  jacobi_eigen_sym(3, MtM, w, V);
+  double S[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double a = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        double iw = (w[k] > 1e-300) ? 1.0 / sqrt(w[k]) : 0.0;
+        a += V[k * 3 + i] * iw * V[k * 3 + j];
+      }
+      S[i * 3 + j] = a;
+    }
+  mat3_mul(M, S, Q);
+}
+
+RCC_HD inline void rodrigues_m2v(const double Rin[9], double r[3])
+{
+  double R[9];
+  orthonormalise3(Rin, R);
+  double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
+  double s = sqrt((vx * vx + vy * vy + vz * vz) * 0.25);
+  double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
+  c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+  double theta = acos(c);
+  if (s < 1e-5) {
+    if (c > 0) { r[0] = r[1] = r[2] = 0.0; return; }
+    double t;
+    t = (R[0] + 1.0) * 0.5; double x = sqrt(t > 0.0 ? t : 0.0);
+    t = (R[4] + 1.0) * 0.5; double y = sqrt(t > 0.0 ? t : 0.0) * (R[1] < 0 ? -1.0 : 1.0);
+    t = (R[8] + 1.0) * 0.5; double z = sqrt(t > 0.0 ? t : 0.0) * (R[2] < 0 ? -1.0 : 1.0);
+    if (fabs(x) < fabs(y) && fabs(x) < fabs(z) && ((R[5] > 0) != (y * z > 0))) z = -z;
+    double nrm = sqrt(x * x + y * y + z * z);
+    double k = theta / nrm;
+    r[0] = x * k; r[1] = y * k; r[2] = z * k;
+    return;
+  }
+  double vv = (1.0 / (2.0 * s)) * theta;
+  r[0] = vx * vv; r[1] = vy * vv; r[2] = vz * vv;
+}
+
+// ---- A.2 one point through undistortPoints (5 fixed iterations) -----------------------------------
+RCC_HD inline void undistort_point(const Cam& cm, bool has_dist, double u, double v, double& xo, double& yo)
+{
+  double x0 = (u - cm.cx) / cm.fx, y0 = (v - cm.cy) / cm.fy;
+  double x = x0, y = y0;
+  if (has_dist) {
+    const double k1 = cm.k[0], k2 = cm.k[1], p1 = cm.k[2], p2 = cm.k[3], k3 = cm.k[4];
+    for (int it = 0; it < 5; ++it) {
+      double r2 = x * x + y * y;
+      double icdist = 1.0 / (1.0 + ((k3 * r2 + k2) * r2 + k1) * r2);
+      double dx = 2.0 * p1 * x * y + p2 * (r2 + 2.0 * x * x);
+      double dy = p1 * (r2 + 2.0 * y * y) + 2.0 * p2 * x * y;
+      x = (x0 - dx) * icdist;
+      y = (y0 - dy) * icdist;
+    }
+  }
+  xo = x; yo = y;
+}
+
+// ---- A.7 one point through projectPoints, with the two Jacobian rows (6 columns each) ------------
+RCC_HD inline void project_point(const double M[3], const double R[9], const double* dRdr, const double t[3],
+                                 const Cam& cm, double uv[2], double* Ju /* 6 or null */, double* Jv)
+{
+  const double* k = cm.k;
+  double X = M[0], Y = M[1], Z = M[2];
+  double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+  double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+  double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+  z = z ? 1.0 / z : 1.0;
+  x *= z; y *= z;
+  double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+  double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
+  double cdist = 1.0 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+  double xd = x * cdist + k[2] * a1 + k[3] * a2;
+  double yd = y * cdist + k[2] * a3 + k[3] * a1;
+  uv[0] = xd * cm.fx + cm.cx;
+  uv[1] = yd * cm.fy + cm.cy;
+  if (!Ju) return;
+  for (int j = 0; j < 6; ++j) {
+    double dxj, dyj;
+    if (j < 3) {
+      const double* d = dRdr + j * 9;
+      double dx0 = X * d[0] + Y * d[1] + Z * d[2];
+      double dy0 = X * d[3] + Y * d[4] + Z * d[5];
+      double dz0 = X * d[6] + Y * d[7] + Z * d[8];
+      dxj = z * (dx0 - x * dz0);
+      dyj = z * (dy0 - y * dz0);
+    } else {
+      int q = j - 3;
+      dxj = (q == 0) ? z : (q == 2 ? -x * z : 0.0);
+      dyj = (q == 1) ? z : (q == 2 ? -y * z : 0.0);
+    }
+    double dr2 = 2.0 * x * dxj + 2.0 * y * dyj;
+    double dcd = k[0] * dr2 + 2.0 * k[1] * r2 * dr2 + 3.0 * k[4] * r4 * dr2;
+    double da1 = 2.0 * (x * dyj + y * dxj);
+    Ju[j] = cm.fx * (dxj * cdist + x * dcd + k[2] * da1 + k[3] * (dr2 + 4.0 * x * dxj));
+    Jv[j] = cm.fy * (dyj * cdist + y * dcd + k[2] * (dr2 + 4.0 * y * dyj) + k[3] * da1);
+  }
+}
+
+// source of points: obj (n x 3), img (n x 2), in any address space the caller can read
+struct Pts {
+  const double* obj;
+  const double* img;
+  int n;
+};
+
+// in-plane coordinates (float32-rounded, as findHomography converts its inputs) of point i
+RCC_HD inline void plane_point(const Pts& p, int i, const double* Rt, const double* Tt, float& Mx, float& My)
+{
+  const double* M = p.obj + 3 * i;
+  Mx = (float)(Rt[0] * M[0] + Rt[1] * M[1] + Rt[2] * M[2] + Tt[0]);
+  My = (float)(Rt[3] * M[0] + Rt[4] * M[1] + Rt[5] * M[2] + Tt[1]);
+}
+RCC_HD inline void norm_point(const Pts& p, int i, const Cam& cm, bool has_dist, float& mx, float& my)
+{
+  double x, y;
+  undistort_point(cm, has_dist, p.img[2 * i], p.img[2 * i + 1], x, y);
+  mx = (float)x; my = (float)y;
+}
+
+// residual sum S = |r|^2 of the homography h (8 params) and, when A != null, JtJ (8x8), Jtr (8),
+// max |r|
+RCC_HD inline double homography_accumulate(const double* h, const Pts& p, const double* Rt, const double* Tt,
+                                           const Cam& cm, bool has_dist, double* A, double* v, double* rinf)
+{
+  if (A) { for (int i = 0; i < 64; ++i) A[i] = 0.0; for (int i = 0; i < 8; ++i) v[i] = 0.0; }
+  double S = 0.0, ri = 0.0;
+  for (int i = 0; i < p.n; ++i) {
+    float Mxf, Myf, mxf, myf;
+    plane_point(p, i, Rt, Tt, Mxf, Myf);
+    norm_point(p, i, cm, has_dist, mxf, myf);
+    double Mx = Mxf, My = Myf;
+    double ww = h[6] * Mx + h[7] * My + 1.0;
+    ww = fabs(ww) > DBL_EPSILON ? 1.0 / ww : 0.0;
+    double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+    double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+    double e0 = xi - (double)mxf, e1 = yi - (double)myf;
+    S += e0 * e0;
+    S += e1 * e1;
+    if (fabs(e0) > ri) ri = fabs(e0);
+    if (fabs(e1) > ri) ri = fabs(e1);
+    if (A) {
+      double a[8] = { Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi };
+      double b[8] = { 0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi };
+      for (int r = 0; r < 8; ++r) {
+        for (int c = 0; c < 8; ++c) A[r * 8 + c] += a[r] * a[c] + b[r] * b[c];
+        v[r] += a[r] * e0 + b[r] * e1;
+      }
+    }
+  }
+  if (rinf) *rinf = ri;
+  return S;
+}
+
+// A.4, N > 4: the LMSolver refinement used by findHomography(method 0), <= 10 iterations
+RCC_HD inline void homography_refine(double* h, const Pts& p, const double* Rt, const double* Tt, const Cam& cm, bool has_dist)
+{
+  const int P = 8, maxIters = 10;
+  const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
+  double x[8], xd[8], A[64], Ap[64], v[8], d[8], Dg[8], tmp[8], T[64], V[64], w[8];
+  for (int i = 0; i < 8; ++i) x[i] = h[i];
+  double rinf = 0.0;
+  double S = homography_accumulate(x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
+  for (int i = 0; i < P; ++i) Dg[i] = A[i * P + i];
+  const double Rlo = 0.25, Rhi = 0.75;
+  double lambda = 1.0, lc = 0.75;
+  int iter = 0;
+  for (;;) {
+    for (int i = 0; i < 64; ++i) Ap[i] = A[i];
+    for (int i = 0; i < P; ++i) Ap[i * P + i] += lambda * Dg[i];
+    sym_solve(P, Ap, v, d, T, V, w);
+    for (int i = 0; i < P; ++i) xd[i] = x[i] - d[i];
+    double Sd = homography_accumulate(xd, p, Rt, Tt, cm, has_dist, nullptr, nullptr, nullptr);
+    double dS = 0.0;
+    for (int a = 0; a < P; ++a) {
+      double s = 0.0;
+      for (int b = 0; b < P; ++b) s += A[a * P + b] * d[b];
+      tmp[a] = -s + 2.0 * v[a];
+      dS += d[a] * tmp[a];
+    }
+    double Rr = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1.0);
+    if (Rr > Rhi) {
+      lambda *= 0.5;
+      if (lambda < lc) lambda = 0.0;
+    } else if (Rr < Rlo) {
+      double t = 0.0;
+      for (int a = 0; a < P; ++a) t += d[a] * v[a];
+      double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1.0) + 2.0;
+      nu = nu < 2.0 ? 2.0 : (nu > 10.0 ? 10.0 : nu);
+      if (lambda == 0.0) {
+        for (int i = 0; i < 64; ++i) T[i] = A[i];
+        jacobi_eigen_sym(P, T, w, V);
+        double thr = 0.0;
+        for (int i = 0; i < P; ++i) thr += fabs(w[i]);
+        thr *= 2.0 * DBL_EPSILON;
+        double maxval = DBL_EPSILON;
+        for (int a = 0; a < P; ++a) {
+          double s = 0.0;
+          for (int i = 0; i < P; ++i) if (fabs(w[i]) > thr) s += V[i * P + a] * V[i * P + a] / w[i];
+          if (fabs(s) > maxval) maxval = fabs(s);
+        }
+        lambda = lc = 1.0 / maxval;
+        nu *= 0.5;
+      }
+      lambda *= nu;
+    }
+    if (Sd < S) {
+      for (int i = 0; i < 8; ++i) x[i] = xd[i];
+      S = homography_accumulate(x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
+    }
+    ++iter;
+    double dinf = 0.0;
+    for (int i = 0; i < P; ++i) if (fabs(d[i]) > dinf) dinf = fabs(d[i]);
+    if (!(iter < maxIters && dinf >= epsx && rinf >= epsf)) break;
+  }
+  for (int i = 0; i < 8; ++i) h[i] = x[i];
+}
+
+// A.4: normalised DLT (+ refinement).  Returns 1 if H is finite.
+RCC_HD inline int find_homography(const Pts& p, const double* Rt, const double* Tt, const Cam& cm, bool has_dist, double H[9])
+{
+  const int n = p.n;
+  double cMx = 0, cMy = 0, cmx = 0, cmy = 0;
+  for (int i = 0; i < n; ++i) {
+    float Mx, My, mx, my;
+    plane_point(p, i, Rt, Tt, Mx, My);
+    norm_point(p, i, cm, has_dist, mx, my);
+    cMx += Mx; cMy += My; cmx += mx; cmy += my;
+  }
+  cMx /= n; cMy /= n; cmx /= n; cmy /= n;
+  double sMx = 0, sMy = 0, smx = 0, smy = 0;
+  for (int i = 0; i < n; ++i) {
+    float Mx, My, mx, my;
+    plane_point(p, i, Rt, Tt, Mx, My);
+    norm_point(p, i, cm, has_dist, mx, my);
+    sMx += fabs(Mx - cMx); sMy += fabs(My - cMy);
+    smx += fabs(mx - cmx); smy += fabs(my - cmy);
+  }
+  if (fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON || fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON) return 0;
+  smx = n / smx; smy = n / smy; sMx = n / sMx; sMy = n / sMy;
+  double invHnorm[9] = { 1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1 };
+  double Hnorm2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
+  double LtL[81], w[9], V[81];
+  for (int i = 0; i < 81; ++i) LtL[i] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    float Mxf, Myf, mxf, myf;
+    plane_point(p, i, Rt, Tt, Mxf, Myf);
+    norm_point(p, i, cm, has_dist, mxf, myf);
+    double x = (mxf - cmx) * smx, y = (myf - cmy) * smy;
+    double X = (Mxf - cMx) * sMx, Y = (Myf - cMy) * sMy;
+    double Lx[9] = { X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x };
+    double Ly[9] = { 0, 0, 0, X, Y, 1, -y * X, -y * Y, -y };
+    for (int j = 0; j < 9; ++j)
+      for (int k = j; k < 9; ++k) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+  }
+  for (int j = 0; j < 9; ++j) for (int k = 0; k < j; ++k) LtL[j * 9 + k] = LtL[k * 9 + j];
+  jacobi_eigen_sym(9, LtL, w, V);
+  double H0[9], T[9];
+  for (int k = 0; k < 9; ++k) H0[k] = V[8 * 9 + k];
+  mat3_mul(invHnorm, H0, T);
+  mat3_mul(T, Hnorm2, H);
+  double s = 1.0 / H[8];
+  for (int k = 0; k < 9; ++k) H[k] *= s;
+  H[8] = 1.0;
+  if (n > 4) homography_refine(H, p, Rt, Tt, cm, has_dist);
+  for (int k = 0; k < 9; ++k) if (!isfinite(H[k])) return 0;
+  return 1;
+}
+
+// normal equations of the pose LM at parameters prm (r,t): A = JtJ (6x6), g = Jte (6); returns |e|^2
+RCC_HD inline double pose_accumulate(const double* prm, const Pts& p, const Cam& cm, double* A, double* g)
+{
+  double R[9], dRdr[27];
+  rodrigues_v2m(prm, R, A ? dRdr : nullptr);
+  if (A) { for (int i = 0; i < 36; ++i) A[i] = 0.0; for (int i = 0; i < 6; ++i) g[i] = 0.0; }
+  double S = 0.0;
+  for (int i = 0; i < p.n; ++i) {
+    double uv[2], Ju[6], Jv[6];
+    project_point(p.obj + 3 * i, R, dRdr, prm + 3, cm, uv, A ? Ju : nullptr, Jv);
+    double e0 = uv[0] - p.img[2 * i], e1 = uv[1] - p.img[2 * i + 1];
+    S += e0 * e0;
+    S += e1 * e1;
+    if (A) {
+      for (int a = 0; a < 6; ++a) {
+        for (int b = 0; b < 6; ++b) A[a * 6 + b] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+        g[a] += Ju[a] * e0 + Jv[a] * e1;
+      }
+    }
+  }
+  return S;
+}
+
+// A.1, A.3, A.5: the initial pose.  Returns a PNP_* status; prm = (r, t).
+RCC_HD inline int pose_init(const Pts& p, const Cam& cm, bool has_dist, double prm[6])
+{
+  const int n = p.n;
+  for (int i = 0; i < 6; ++i) prm[i] = 0.0;
+  if (n < 4) return PNP_TOO_FEW;
+  double Mc[3] = { 0, 0, 0 };
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) Mc[k] += p.obj[3 * i + k];
+  for (int k = 0; k < 3; ++k) Mc[k] /= n;
+  double MM[9];
+  for (int i = 0; i < 9; ++i) MM[i] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double d[3] = { p.obj[3 * i] - Mc[0], p.obj[3 * i + 1] - Mc[1], p.obj[3 * i + 2] - Mc[2] };
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) MM[a * 3 + b] += d[a] * d[b];
+  }
+  double W[3], Vt[9];
+  jacobi_eigen_sym(3, MM, W, Vt);
+  if (!(W[2] / W[1] < 1e-3)) return PNP_NONPLANAR;
+  double Rt[9];
+  for (int k = 0; k < 9; ++k) Rt[k] = Vt[k];
+  if (Vt[2] * Vt[2] + Vt[5] * Vt[5] < 1e-10) {
+    for (int k = 0; k < 9; ++k) Rt[k] = (k % 4 == 0) ? 1.0 : 0.0;
+  }
+  if (mat3_det(Rt) < 0) for (int k = 0; k < 9; ++k) Rt[k] = -Rt[k];
+  double Tt[3];
+  for (int a = 0; a < 3; ++a) Tt[a] = -(Rt[a * 3] * Mc[0] + Rt[a * 3 + 1] * Mc[1] + Rt[a * 3 + 2] * Mc[2]);
+  double H[9], R[9], t[3], r[3];
+  int status = PNP_OK;
+  if (find_homography(p, Rt, Tt, cm, has_dist, H)) {
+    double h1[3] = { H[0], H[3], H[6] }, h2[3] = { H[1], H[4], H[7] };
+    t[0] = H[2]; t[1] = H[5]; t[2] = H[8];
+    double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
+    double n2 = sqrt(h2[0] * h2[0] + h2[1] * h2[1] + h2[2] * h2[2]);
+    for (int k = 0; k < 3; ++k) { h1[k] /= n1; h2[k] /= n2; t[k] *= 2.0 / (n1 + n2); }
+    double h3[3] = { h1[1] * h2[2] - h1[2] * h2[1], h1[2] * h2[0] - h1[0] * h2[2], h1[0] * h2[1] - h1[1] * h2[0] };
+    double R0[9] = { h1[0], h2[0], h3[0], h1[1], h2[1], h3[1], h1[2], h2[2], h3[2] };
+    rodrigues_m2v(R0, r);
+    rodrigues_v2m(r, R, nullptr);
+    double t2[3];
+    for (int a = 0; a < 3; ++a) t2[a] = R[a * 3] * Tt[0] + R[a * 3 + 1] * Tt[1] + R[a * 3 + 2] * Tt[2] + t[a];
+    for (int a = 0; a < 3; ++a) t[a] = t2[a];
+    mat3_mul(R, Rt, R);
+  } else {
+    status = PNP_DEGENERATE;
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    t[0] = t[1] = t[2] = 0.0;
+  }
+  rodrigues_m2v(R, r);
+  for (int k = 0; k < 3; ++k) { prm[k] = r[k]; prm[3 + k] = t[k]; }
+  return status;
+}
+
+// A.8: CvLevMarq, (J, err) form, 6 free parameters.  `accum(prm, A, g)` returns |e|^2 and fills
+// A, g when A != null -- it is the only place the points are touched, so a caller can supply a
+// wave-parallel (or MFMA) accumulation.
+template <class Accum>
+RCC_HD inline int pose_lm(double p[6], Accum accum, double* rms_sq_sum)
+{
+  double pprev[6], A[36], g[6], Ap[36], dl[6], T[36], V[36], w[6];
+  int L = -3, it = 0;
+  double prevErr = 0.0;
+  const int max_iter = 20;
+  const double eps = FLT_EPSILON;
+  for (;;) {
+    double S0 = accum(p, A, g);
+    for (int a = 0; a < 6; ++a) pprev[a] = p[a];
+    if (it == 0) prevErr = sqrt(S0);
+    double errNorm;
+    for (;;) {
+      double lambda = exp((double)L * log(10.0));
+      for (int i = 0; i < 36; ++i) Ap[i] = A[i];
+      for (int a = 0; a < 6; ++a) Ap[a * 6 + a] *= 1.0 + lambda;
+      sym_solve(6, Ap, g, dl, T, V, w);
+      for (int a = 0; a < 6; ++a) p[a] = pprev[a] - dl[a];
+      errNorm = sqrt(accum(p, (double*)nullptr, (double*)nullptr));
+      if (errNorm > prevErr) {
+        if (++L <= 16) continue;
+      }
+      break;
+    }
+    L = (L - 1 > -16) ? L - 1 : -16;
+    double dn = 0.0, pn = 0.0;
+    for (int a = 0; a < 6; ++a) { dn += (p[a] - pprev[a]) * (p[a] - pprev[a]); pn += pprev[a] * pprev[a]; }
+    double rel = sqrt(dn) / sqrt(pn);
+    if (++it >= max_iter || rel < eps) break;
+    prevErr = errNorm;
+  }
+  if (rms_sq_sum) *rms_sq_sum = accum(p, (double*)nullptr, (double*)nullptr);
+  return it;
+}
+
+struct SerialAccum {
+  Pts p;
+  Cam cm;
+  RCC_HD double operator()(const double* prm, double* A, double* g) const { return pose_accumulate(prm, p, cm, A, g); }
+};
+
+// whole solve, one thread
+RCC_HD inline int solve_pnp(const Pts& p, const Cam& cm_in, int dist_model, double rvec[3], double tvec[3], double* rms, int* iters)
+{
+  Cam cm = cm_in;
+  const bool has_dist = (dist_model == RCC_DIST_PLUMB_BOB);
+  if (!has_dist) for (int i = 0; i < 5; ++i) cm.k[i] = 0.0;
+  double prm[6];
+  if (rms) *rms = 0.0;
+  if (iters) *iters = 0;
+  int status = pose_init(p, cm, has_dist, prm);
+  if (status == PNP_TOO_FEW || status == PNP_NONPLANAR) {
+    for (int k = 0; k < 3; ++k) { rvec[k] = 0.0; tvec[k] = 0.0; }
+    return status;
+  }
+  SerialAccum acc{ p, cm };
+  double ss = 0.0;
+  int it = pose_lm(prm, acc, &ss);
+  for (int k = 0; k < 3; ++k) { rvec[k] = prm[k]; tvec[k] = prm[3 + k]; }
+  if (rms) *rms = sqrt(ss / p.n);
+  if (iters) *iters = it;
+  return status;
+}
+
+}  // namespace rccpnp

@@ -1,0 +1,485 @@
+// rcc_api.hip -- host side of the C ABI declared in include/rcc.h: handle life cycle, argument
+// checking, stream-ordered launches of the stage kernels, result hand-over.
+//
+// Each entry point stands in for a reference interface (cited in include/rcc.h):
+//   rcc_detect_batch     <- the "tag_detections" publisher consumed at corner_detections.cpp:41-56,78
+//   rcc_solve_pnp_batch  <- cv::solvePnP(..., false, CV_ITERATIVE) at camera_pose.cpp:163
+//   rcc_rodrigues_*      <- cv::Rodrigues at camera_pose.cpp:93,116,164 / opt_visualization.cpp:36
+// Nothing here falls back to a CPU implementation: without a HIP device rcc_create fails with
+// RCC_ERR_DEVICE.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <new>
+#include <vector>
+#include "rcc_internal.h"
+#include "pnp_core.h"
+
+#define HIPCHK(h, expr)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      if (h) snprintf((h)->err, sizeof((h)->err), "%s: %s", #expr, hipGetErrorString(e_)); \
+      return RCC_ERR_DEVICE;                                                              \
+    }                                                                                     \
+  } while (0)
+
+extern "C" {
+
+int rcc_abi_version(void) { return RCC_ABI_VERSION; }
+
+const char* rcc_status_string(int s)
+{
+  switch (s) {
+    case RCC_OK: return "ok";
+    case RCC_ERR_ARG: return "invalid argument";
+    case RCC_ERR_UNSUPPORTED: return "unsupported configuration";
+    case RCC_ERR_DEVICE: return "HIP device error";
+    case RCC_ERR_CAPACITY: return "batch exceeds handle capacity";
+    case RCC_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+const char* rcc_last_device_error(const rcc_handle* h) { return h ? h->err : ""; }
+
+void rcc_default_config(rcc_config* c)
+{
+  if (!c) return;
+  memset(c, 0, sizeof(*c));
+  c->struct_size = sizeof(rcc_config);
+  c->abi_version = RCC_ABI_VERSION;
+  c->width = 640; c->height = 480; c->stride_bytes = 640 * 3; c->pixfmt = RCC_PIX_BGR8;
+  c->frame_bytes = (int64_t)640 * 3 * 480;
+  c->K[0] = c->K[4] = 0.9 * 640; c->K[2] = (640 - 1) * 0.5; c->K[5] = (480 - 1) * 0.5; c->K[8] = 1.0;
+  c->dist_model = RCC_DIST_PLUMB_BOB;
+  c->undistort = 1;
+  c->D[0] = -0.28; c->D[1] = 0.07; c->D[2] = 2e-4; c->D[3] = -1e-4; c->D[4] = 0.0;
+  c->thr_min_contrast = 32;
+  c->harris_thresh = 200000;
+  c->cand_margin = 8;
+  c->max_candidates = 2048;
+  c->nms_radius = 5;
+  c->xj_check = 1;
+  c->max_kept = 256;
+  c->subpix_win = 5;
+  c->subpix_max_iter = 30;
+  c->subpix_eps = 1e-3;
+  c->target_kind = RCC_TARGET_CHECKERBOARD;
+  c->board_cols = 8; c->board_rows = 6; c->board_square = 0.108; c->board_id = 0;
+  c->max_targets = 1;
+  c->reference_mode = 0;
+  c->pnp_use_mfma = 0;
+  c->device = 0;
+  c->batch_capacity = 16;
+}
+
+static int validate(const rcc_config* c)
+{
+  if (!c) return RCC_ERR_ARG;
+  if (c->struct_size != sizeof(rcc_config) || c->abi_version != RCC_ABI_VERSION) return RCC_ERR_ARG;
+  if (c->width < 1 || c->height < 1 || c->width > 16384 || c->height > 16384) return RCC_ERR_ARG;
+  if (c->pixfmt != RCC_PIX_MONO8 && c->pixfmt != RCC_PIX_BGR8) return RCC_ERR_ARG;
+  const int ch = c->pixfmt == RCC_PIX_BGR8 ? 3 : 1;
+  if (c->stride_bytes < c->width * ch) return RCC_ERR_ARG;
+  if (c->frame_bytes < (int64_t)c->stride_bytes * c->height) return RCC_ERR_ARG;
+  if (c->dist_model < RCC_DIST_NONE || c->dist_model > RCC_DIST_FISHEYE) return RCC_ERR_ARG;
+  if (!(c->K[0] > 0.0) || !(c->K[4] > 0.0)) return RCC_ERR_ARG;
+  if (c->max_candidates < 1 || c->max_candidates > 4096) return RCC_ERR_ARG;
+  if (c->max_kept < 1 || c->max_kept > RCC_MAX_KEPT) return RCC_ERR_ARG;
+  if (c->subpix_win < 1 || c->subpix_win > 7 || c->subpix_max_iter < 1) return RCC_ERR_ARG;
+  if (c->nms_radius < 0 || c->cand_margin < 0) return RCC_ERR_ARG;
+  if (c->batch_capacity < 1) return RCC_ERR_ARG;
+  if (c->max_targets < 1) return RCC_ERR_ARG;
+  if (c->target_kind == RCC_TARGET_CHECKERBOARD) {
+    if (c->board_cols < 2 || c->board_rows < 2 || c->board_cols > 16 || c->board_rows > 16) return RCC_ERR_ARG;
+    if (c->board_cols * c->board_rows > RCC_MAX_BOARD_CORNERS || !(c->board_square > 0.0)) return RCC_ERR_ARG;
+  } else if (c->target_kind == RCC_TARGET_FIDUCIAL) {
+    return RCC_ERR_UNSUPPORTED;   // multi-fiducial path: SURVEY 8(a) a4/a6 second form, not in this round
+  } else {
+    return RCC_ERR_ARG;
+  }
+  // solvePnP has no fisheye model (the reference only has the 5-coefficient plumb-bob,
+  // camera_pose.cpp:39): fisheye frames must be undistorted first
+  if (c->dist_model == RCC_DIST_FISHEYE && !c->undistort) return RCC_ERR_UNSUPPORTED;
+  return RCC_OK;
+}
+
+void rcc_destroy(rcc_handle* h)
+{
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = { h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
+                   h->d_kept, h->d_kept_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
+                   h->d_board_obj, h->d_img_scratch };
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->h_det) (void)hipHostFree(h->h_det);
+  if (h->h_ndet) (void)hipHostFree(h->h_ndet);
+  for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int rcc_create(const rcc_config* cfg, rcc_handle** out)
+{
+  if (!out) return RCC_ERR_ARG;
+  *out = nullptr;
+  int v = validate(cfg);
+  if (v != RCC_OK) return v;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev) return RCC_ERR_DEVICE;
+  rcc_handle* h = new (std::nothrow) rcc_handle();
+  if (!h) return RCC_ERR_NOMEM;
+  memset(h, 0, sizeof(*h));
+  h->cfg = *cfg;
+  h->device = cfg->device;
+  h->undist = cfg->undistort && cfg->dist_model != RCC_DIST_NONE;
+  h->dense_variant = -1;
+  h->ingest_variant = -1;
+  h->sp.win = cfg->subpix_win;
+  h->sp.max_iter = cfg->subpix_max_iter;
+  h->sp.eps2 = cfg->subpix_eps * cfg->subpix_eps;
+  for (int k = -cfg->subpix_win; k <= cfg->subpix_win; ++k) {
+    double t = (double)k / (double)cfg->subpix_win;
+    h->sp.m1[k + cfg->subpix_win] = exp(-(t * t));   // host libm, as the specification does
+  }
+  const size_t B = (size_t)cfg->batch_capacity, px = (size_t)cfg->width * cfg->height;
+#define ALLOC(ptr, bytes)                                                                           \
+  do {                                                                                              \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                             \
+    if (e_ != hipSuccess) { rcc_destroy(h); return e_ == hipErrorOutOfMemory ? RCC_ERR_NOMEM : RCC_ERR_DEVICE; } \
+  } while (0)
+  if (hipSetDevice(h->device) != hipSuccess) { delete h; return RCC_ERR_DEVICE; }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RCC_ERR_DEVICE; }
+  for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
+  ALLOC(h->d_grey, B * px);
+  ALLOC(h->d_bin, B * px);
+  ALLOC(h->d_cand, B * (size_t)cfg->max_candidates * sizeof(rcc_cand));
+  ALLOC(h->d_cand_count, B * sizeof(int32_t));
+  ALLOC(h->d_pre, B * RCC_MAX_KEPT * sizeof(rcc_cand));
+  ALLOC(h->d_npre, B * sizeof(int32_t));
+  ALLOC(h->d_pre_xy, B * RCC_MAX_KEPT * 2 * sizeof(double));
+  ALLOC(h->d_kept, B * RCC_MAX_KEPT * sizeof(rcc_cand));
+  ALLOC(h->d_kept_xy, B * RCC_MAX_KEPT * 2 * sizeof(double));
+  ALLOC(h->d_fc, B * sizeof(rcc_frame_corners));
+  ALLOC(h->d_det, B * (size_t)cfg->max_targets * sizeof(rcc_detection));
+  ALLOC(h->d_ndet, B * sizeof(int32_t));
+  ALLOC(h->d_img_scratch, B * 2 * RCC_MAX_BOARD_CORNERS * sizeof(double));
+  ALLOC(h->d_board_obj, 3 * RCC_MAX_BOARD_CORNERS * sizeof(double));
+  if (hipHostMalloc((void**)&h->h_det, B * (size_t)cfg->max_targets * sizeof(rcc_detection)) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_ndet, B * sizeof(int32_t)) != hipSuccess) { rcc_destroy(h); return RCC_ERR_NOMEM; }
+  {
+    // object points of the board: index = row*cols + col, x right, y up, z = 0, origin at the
+    // centre -- the object-frame convention of camera_pose.cpp:158-161
+    std::vector<double> obj(3 * RCC_MAX_BOARD_CORNERS, 0.0);
+    for (int r = 0; r < cfg->board_rows; ++r)
+      for (int c = 0; c < cfg->board_cols; ++c) {
+        double* o = &obj[3 * (r * cfg->board_cols + c)];
+        o[0] = ((double)c - 0.5 * (double)(cfg->board_cols - 1)) * cfg->board_square;
+        o[1] = (0.5 * (double)(cfg->board_rows - 1) - (double)r) * cfg->board_square;
+        o[2] = 0.0;
+      }
+    if (hipMemcpy(h->d_board_obj, obj.data(), obj.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      rcc_destroy(h);
+      return RCC_ERR_DEVICE;
+    }
+  }
+  *out = h;
+  return RCC_OK;
+}
+
+int rcc_set_dense_variant(rcc_handle* h, int variant)
+{
+  if (!h) return RCC_ERR_ARG;
+  int p = h->dense_variant;
+  h->dense_variant = variant;
+  return p;
+}
+int rcc_set_ingest_variant(rcc_handle* h, int variant)
+{
+  if (!h) return RCC_ERR_ARG;
+  int p = h->ingest_variant;
+  h->ingest_variant = variant;
+  return p;
+}
+
+int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n)
+{
+  if (!h || !ms) return RCC_ERR_ARG;
+  int k = n < 5 ? n : 5;
+  for (int i = 0; i < k; ++i) ms[i] = h->last_ms[i];
+  return k;
+}
+
+// ---- stages ------------------------------------------------------------------------------------
+int rcc_stage_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey, void* stream)
+{
+  if (!h || !d_frames || !d_grey || nframes < 0) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  HIPCHK(h, rcc_launch_ingest(h, (const uint8_t*)d_frames, nframes, (uint8_t*)d_grey, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return RCC_OK;
+}
+
+int rcc_stage_threshold_corner(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_bin,
+                               void* d_cand, void* d_cand_count, void* stream)
+{
+  if (!h || !d_grey || !d_bin || !d_cand || !d_cand_count || nframes < 0) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey, nframes, (uint8_t*)d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return RCC_OK;
+}
+
+int rcc_time_dense(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_bin, void* d_cand,
+                   void* d_cand_count, int32_t reps, float* mean_ms)
+{
+  if (!h || !d_grey || !d_bin || !d_cand || !d_cand_count || nframes < 1 || reps < 1 || !mean_ms) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  // the count reset (a tiny memset) is part of every launch of the pass; it stays inside
+  HIPCHK(h, hipEventRecord(h->ev[6], s));
+  for (int r = 0; r < reps; ++r)
+    HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey, nframes, (uint8_t*)d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, s));
+  HIPCHK(h, hipEventRecord(h->ev[7], s));
+  HIPCHK(h, hipEventSynchronize(h->ev[7]));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
+  *mean_ms = ms / reps;
+  return RCC_OK;
+}
+
+int rcc_time_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey, int32_t reps, float* mean_ms)
+{
+  if (!h || !d_frames || !d_grey || nframes < 1 || reps < 1 || !mean_ms) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipEventRecord(h->ev[6], s));
+  for (int r = 0; r < reps; ++r) HIPCHK(h, rcc_launch_ingest(h, (const uint8_t*)d_frames, nframes, (uint8_t*)d_grey, s));
+  HIPCHK(h, hipEventRecord(h->ev[7], s));
+  HIPCHK(h, hipEventSynchronize(h->ev[7]));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
+  *mean_ms = ms / reps;
+  return RCC_OK;
+}
+
+// list + subpix + validate/grid + pnp, then results to the host.  Events: ev[2]..ev[5].
+static int run_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, const rcc_cand* d_cand,
+                       const int32_t* d_cand_count, int nframes, rcc_detection* det, int32_t* ndet,
+                       rcc_frame_corners* corners, hipStream_t s)
+{
+  HIPCHK(h, hipEventRecord(h->ev[2], s));
+  HIPCHK(h, rcc_launch_list(h, d_cand, d_cand_count, nframes, s));
+  HIPCHK(h, rcc_launch_subpix(h, d_grey, nframes, s));
+  HIPCHK(h, rcc_launch_grid(h, d_bin, nframes, s));
+  HIPCHK(h, hipEventRecord(h->ev[3], s));
+  HIPCHK(h, rcc_launch_pnp_board(h, nframes, s));
+  HIPCHK(h, hipEventRecord(h->ev[4], s));
+  HIPCHK(h, hipMemcpyAsync(h->h_det, h->d_det, sizeof(rcc_detection) * (size_t)nframes, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->h_ndet, h->d_ndet, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost, s));
+  if (corners) HIPCHK(h, hipMemcpyAsync(corners, h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipEventRecord(h->ev[5], s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  int n = 0;
+  for (int f = 0; f < nframes; ++f)
+    if (h->h_ndet[f] > 0) {
+      if (det) det[n] = h->h_det[f];
+      ++n;
+    }
+  if (ndet) *ndet = n;
+  (void)hipEventElapsedTime(&h->last_ms[2], h->ev[2], h->ev[3]);
+  (void)hipEventElapsedTime(&h->last_ms[3], h->ev[3], h->ev[4]);
+  (void)hipEventElapsedTime(&h->last_ms[4], h->ev[4], h->ev[5]);
+  return RCC_OK;
+}
+
+int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, const void* d_cand,
+                      const void* d_cand_count, int32_t nframes, rcc_detection* det, int32_t* ndet,
+                      rcc_frame_corners* corners, void* stream)
+{
+  if (!h || !d_grey || !d_bin || !d_cand || !d_cand_count || nframes < 0) return RCC_ERR_ARG;
+  if (nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  return run_targets(h, (const uint8_t*)d_grey, (const uint8_t*)d_bin, (const rcc_cand*)d_cand,
+                     (const int32_t*)d_cand_count, nframes, det, ndet, corners, s);
+}
+
+int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t frames_mem,
+                     rcc_detection* det, int32_t* ndet, rcc_frame_corners* corners, void* stream)
+{
+  if (!h || (!frames && nframes > 0) || nframes < 0) return RCC_ERR_ARG;
+  if (frames_mem != RCC_MEM_HOST && frames_mem != RCC_MEM_DEVICE) return RCC_ERR_ARG;
+  if (nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
+  if (ndet) *ndet = 0;
+  if (nframes == 0) return RCC_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const uint8_t* d_frames = (const uint8_t*)frames;
+  if (frames_mem == RCC_MEM_HOST) {
+    size_t need = (size_t)h->cfg.frame_bytes * nframes;
+    if (need > h->stage_bytes) {
+      if (h->d_stage) (void)hipFree(h->d_stage);
+      h->d_stage = nullptr;
+      h->stage_bytes = 0;
+      size_t cap = (size_t)h->cfg.frame_bytes * h->cfg.batch_capacity;
+      if (hipMalloc((void**)&h->d_stage, cap) != hipSuccess) return RCC_ERR_NOMEM;
+      h->stage_bytes = cap;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_stage, frames, need, hipMemcpyHostToDevice, s));
+    d_frames = h->d_stage;
+  }
+  HIPCHK(h, hipEventRecord(h->ev[0], s));
+  HIPCHK(h, rcc_launch_ingest(h, d_frames, nframes, h->d_grey, s));
+  HIPCHK(h, hipEventRecord(h->ev[1], s));
+  HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
+  int r = run_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, det, ndet, corners, s);
+  if (r != RCC_OK) return r;
+  (void)hipEventElapsedTime(&h->last_ms[0], h->ev[0], h->ev[1]);
+  (void)hipEventElapsedTime(&h->last_ms[1], h->ev[1], h->ev[2]);
+  return RCC_OK;
+}
+
+// debug/parity taps: copy the handle's intermediate lists of the last batch to the host
+int rcc_debug_fetch_lists(rcc_handle* h, int32_t nframes, void* pre /*B*256 cand*/, int32_t* npre,
+                          double* pre_xy, void* kept, double* kept_xy)
+{
+  if (!h || nframes < 0 || nframes > h->cfg.batch_capacity) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = (size_t)nframes;
+  if (pre) HIPCHK(h, hipMemcpy(pre, h->d_pre, n * RCC_MAX_KEPT * sizeof(rcc_cand), hipMemcpyDeviceToHost));
+  if (npre) HIPCHK(h, hipMemcpy(npre, h->d_npre, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (pre_xy) HIPCHK(h, hipMemcpy(pre_xy, h->d_pre_xy, n * RCC_MAX_KEPT * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  if (kept) HIPCHK(h, hipMemcpy(kept, h->d_kept, n * RCC_MAX_KEPT * sizeof(rcc_cand), hipMemcpyDeviceToHost));
+  if (kept_xy) HIPCHK(h, hipMemcpy(kept_xy, h->d_kept_xy, n * RCC_MAX_KEPT * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  return RCC_OK;
+}
+int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin, void* cand, int32_t* cand_count)
+{
+  if (!h || nframes < 0 || nframes > h->cfg.batch_capacity) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = (size_t)nframes, px = (size_t)h->cfg.width * h->cfg.height;
+  if (grey) HIPCHK(h, hipMemcpy(grey, h->d_grey, n * px, hipMemcpyDeviceToHost));
+  if (bin) HIPCHK(h, hipMemcpy(bin, h->d_bin, n * px, hipMemcpyDeviceToHost));
+  if (cand) HIPCHK(h, hipMemcpy(cand, h->d_cand, n * (size_t)h->cfg.max_candidates * sizeof(rcc_cand), hipMemcpyDeviceToHost));
+  if (cand_count) HIPCHK(h, hipMemcpy(cand_count, h->d_cand_count, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return RCC_OK;
+}
+
+// ---- solvePnP / Rodrigues drop-ins -----------------------------------------------------------------
+static int ensure_pnp_buf(rcc_handle* h, size_t bytes)
+{
+  if (bytes <= h->pnp_buf_bytes) return RCC_OK;
+  if (h->d_pnp_buf) (void)hipFree(h->d_pnp_buf);
+  h->d_pnp_buf = nullptr;
+  h->pnp_buf_bytes = 0;
+  size_t cap = bytes + bytes / 2 + 4096;
+  if (hipMalloc((void**)&h->d_pnp_buf, cap) != hipSuccess) return RCC_ERR_NOMEM;
+  h->pnp_buf_bytes = cap;
+  return RCC_OK;
+}
+
+int rcc_solve_pnp_batch(rcc_handle* h, const double* obj, const double* img, const int32_t* npts,
+                        int32_t ntargets, const double* K, const double* D, int32_t dist_model,
+                        double* rvec, double* tvec, double* rms, int32_t* status, int32_t* iters)
+{
+  if (!h || ntargets < 0 || (ntargets > 0 && (!obj || !img || !npts || !rvec || !tvec))) return RCC_ERR_ARG;
+  if (ntargets == 0) return RCC_OK;
+  if (dist_model != RCC_DIST_NONE && dist_model != RCC_DIST_PLUMB_BOB) return RCC_ERR_UNSUPPORTED;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<int32_t> off((size_t)ntargets);
+  size_t total = 0;
+  for (int t = 0; t < ntargets; ++t) {
+    if (npts[t] < 0) return RCC_ERR_ARG;
+    off[t] = (int32_t)total;
+    total += (size_t)npts[t];
+  }
+  const size_t T = (size_t)ntargets;
+  // layout (8-byte units): obj[3*total] img[2*total] rvec[3T] tvec[3T] rms[T] | int32: off[T] npts[T] status[T] iters[T]
+  const size_t nd = 5 * total + 7 * T;
+  const size_t bytes = nd * sizeof(double) + 4 * T * sizeof(int32_t);
+  int r = ensure_pnp_buf(h, bytes);
+  if (r != RCC_OK) return r;
+  double* d_obj = h->d_pnp_buf;
+  double* d_img = d_obj + 3 * total;
+  double* d_rvec = d_img + 2 * total;
+  double* d_tvec = d_rvec + 3 * T;
+  double* d_rms = d_tvec + 3 * T;
+  int32_t* d_off = (int32_t*)(d_rms + T);
+  int32_t* d_npts = d_off + T;
+  int32_t* d_status = d_npts + T;
+  int32_t* d_iters = d_status + T;
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipMemcpyAsync(d_obj, obj, 3 * total * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(d_img, img, 2 * total * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(d_off, off.data(), T * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(d_npts, npts, T * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  rcc_cam cam;
+  const double* Kp = K ? K : h->cfg.K;
+  const double* Dp = D ? D : h->cfg.D;
+  cam.fx = Kp[0]; cam.cx = Kp[2]; cam.fy = Kp[4]; cam.cy = Kp[5];
+  for (int i = 0; i < 8; ++i) cam.D[i] = (i < 5) ? Dp[i] : 0.0;
+  cam.model = dist_model;
+  HIPCHK(h, rcc_launch_pnp_generic(h, d_obj, d_img, d_off, d_npts, ntargets, cam, d_rvec, d_tvec, d_rms, d_status, d_iters, s));
+  HIPCHK(h, hipMemcpyAsync(rvec, d_rvec, 3 * T * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(tvec, d_tvec, 3 * T * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (rms) HIPCHK(h, hipMemcpyAsync(rms, d_rms, T * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (status) HIPCHK(h, hipMemcpyAsync(status, d_status, T * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (iters) HIPCHK(h, hipMemcpyAsync(iters, d_iters, T * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return RCC_OK;
+}
+
+static int rodrigues_batch(rcc_handle* h, int dir, const double* in, int32_t n, double* out)
+{
+  if (!h || n < 0 || (n > 0 && (!in || !out))) return RCC_ERR_ARG;
+  if (n == 0) return RCC_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t nin = (dir == 0 ? 3 : 9) * (size_t)n, nout = (dir == 0 ? 9 : 3) * (size_t)n;
+  int r = ensure_pnp_buf(h, (nin + nout) * sizeof(double));
+  if (r != RCC_OK) return r;
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipMemcpyAsync(h->d_pnp_buf, in, nin * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(h, rcc_launch_rodrigues(dir, h->d_pnp_buf, n, h->d_pnp_buf + nin, s));
+  HIPCHK(h, hipMemcpyAsync(out, h->d_pnp_buf + nin, nout * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return RCC_OK;
+}
+int rcc_rodrigues_v2m_batch(rcc_handle* h, const double* rvec, int32_t n, double* R9) { return rodrigues_batch(h, 0, rvec, n, R9); }
+int rcc_rodrigues_m2v_batch(rcc_handle* h, const double* R9, int32_t n, double* rvec) { return rodrigues_batch(h, 1, R9, n, rvec); }
+
+// ---- synthetic camera ------------------------------------------------------------------------------
+int rcc_synth_render_batch(rcc_handle* h, const rcc_synth_params* sp, const double* poses,
+                           int32_t nframes, int32_t first_frame_index, void* d_frames, void* stream)
+{
+  if (!h || !sp || sp->struct_size != sizeof(rcc_synth_params) || !poses || !d_frames || nframes < 0) return RCC_ERR_ARG;
+  if (nframes == 0) return RCC_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  std::vector<double> hinv(9 * (size_t)nframes);
+  for (int f = 0; f < nframes; ++f) {
+    const double* p = poses + 6 * (size_t)f;
+    double R[9];
+    rccpnp::rodrigues_v2m(p, R, nullptr);
+    const double M[9] = { R[0], R[1], p[3], R[3], R[4], p[4], R[6], R[7], p[5] };
+    const double d = rccpnp::mat3_det(M);
+    const double q = 1.0 / d;
+    double* I = &hinv[9 * (size_t)f];
+    I[0] = (M[4] * M[8] - M[5] * M[7]) * q; I[1] = (M[2] * M[7] - M[1] * M[8]) * q; I[2] = (M[1] * M[5] - M[2] * M[4]) * q;
+    I[3] = (M[5] * M[6] - M[3] * M[8]) * q; I[4] = (M[0] * M[8] - M[2] * M[6]) * q; I[5] = (M[2] * M[3] - M[0] * M[5]) * q;
+    I[6] = (M[3] * M[7] - M[4] * M[6]) * q; I[7] = (M[1] * M[6] - M[0] * M[7]) * q; I[8] = (M[0] * M[4] - M[1] * M[3]) * q;
+  }
+  int r = ensure_pnp_buf(h, hinv.size() * sizeof(double));
+  if (r != RCC_OK) return r;
+  HIPCHK(h, hipMemcpyAsync(h->d_pnp_buf, hinv.data(), hinv.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(h, rcc_launch_synth(h, sp, h->d_pnp_buf, nframes, first_frame_index, (uint8_t*)d_frames, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return RCC_OK;
+}
+
+}  // extern "C"

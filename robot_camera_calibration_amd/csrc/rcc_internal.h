@@ -1,0 +1,79 @@
+// rcc_internal.h -- shared declarations of the HIP implementation behind include/rcc.h.
+// gfx950 (MI355X) only; wavefront = 64.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rcc.h"
+
+#define RCC_WAVE 64
+#define RCC_MAX_KEPT 256
+
+struct rcc_cand {  // dense-pass list entry, 8 bytes
+  int16_t x, y;
+  int32_t score;
+};
+
+// camera parameters passed by value to kernels
+struct rcc_cam {
+  double fx, fy, cx, cy;
+  double D[8];
+  int model;
+};
+
+struct rcc_subpix_params {
+  int win, max_iter;
+  double eps2;
+  double m1[15];  // exp(-(k/win)^2), k=-win..win, computed on the host (libm)
+};
+
+struct rcc_handle {
+  rcc_config cfg;
+  int device;
+  hipStream_t stream;
+  int undist;  // cfg.undistort && model != NONE
+  // scratch sized for batch_capacity frames
+  uint8_t* d_grey;
+  uint8_t* d_bin;
+  rcc_cand* d_cand;
+  int32_t* d_cand_count;
+  rcc_cand* d_pre;        // B x 256
+  int32_t* d_npre;        // B
+  double* d_pre_xy;       // B x 256 x 2
+  rcc_cand* d_kept;       // B x 256 (validated, rounded refined pixel)
+  double* d_kept_xy;      // B x 256 x 2
+  rcc_frame_corners* d_fc;  // B
+  rcc_detection* d_det;     // B x max_targets
+  int32_t* d_ndet;          // B
+  uint8_t* d_stage;         // staging for host-resident input frames
+  size_t stage_bytes;
+  // pnp batch scratch (grown on demand)
+  double* d_pnp_buf;
+  size_t pnp_buf_bytes;
+  rcc_detection* h_det;     // pinned
+  int32_t* h_ndet;          // pinned
+  double* d_board_obj;      // 256 x 3 object points of the board
+  double* d_img_scratch;    // B x 256 x 2 image points handed to the solver
+  hipEvent_t ev[8];
+  float last_ms[5];
+  int dense_variant, ingest_variant;
+  rcc_subpix_params sp;
+  char err[256];
+};
+
+// ---- launchers (each returns hipError_t of the launch) ---------------------------------------
+hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes, uint8_t* d_grey, hipStream_t s);
+hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
+                            rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
+hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t* d_cand_count,
+                           int nframes, hipStream_t s);
+hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);
+hipError_t rcc_launch_grid(rcc_handle* h, const uint8_t* d_bin, int nframes, hipStream_t s);
+hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s);
+hipError_t rcc_launch_pnp_generic(rcc_handle* h, const double* d_obj, const double* d_img,
+                                  const int32_t* d_off, const int32_t* d_npts, int ntargets,
+                                  rcc_cam cam, double* d_rvec, double* d_tvec, double* d_rms,
+                                  int32_t* d_status, int32_t* d_iters, hipStream_t s);
+hipError_t rcc_launch_rodrigues(int dir, const double* d_in, int n, double* d_out, hipStream_t s);
+hipError_t rcc_launch_synth(rcc_handle* h, const rcc_synth_params* sp, const double* d_poses,
+                            int nframes, int first_index, uint8_t* d_frames, hipStream_t s);

@@ -1,0 +1,242 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same bytes.
+
+Bars (BASELINE.json north_star): bit-exact for every integer output (grey, threshold map,
+candidate list, suppressed list, validated list, corner indices); <= 1e-4 for sub-pixel corner
+positions (px), rvec (rad) and tvec (m).  The reference holds no fixtures for this path
+(SURVEY.md 8(c)): parity is against the oracle, which is itself unpinned -- see oracle/orc.h.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from robot_camera_calibration_amd import abi, api, synth
+from tests.util import clone_cfg, fc_px, fc_xy, sorted_cands
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch
+
+
+def _make(cfg_mod=None, w=640, h=480, pixfmt=abi.RCC_PIX_BGR8, B=6):
+    cfg = api.default_config()
+    abi.set_geometry(cfg, w, h, pixfmt)
+    cfg.batch_capacity = B
+    if cfg_mod:
+        cfg_mod(cfg)
+    return cfg
+
+
+def _render(torch, det, cfg, n, seed=0xC0FFEE, **kw):
+    sp = abi.default_synth_params(seed=seed)
+    poses = synth.sample_poses(n, cfg, seed=seed, **kw)
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    return frames, poses
+
+
+def _check_batch(torch, oracle, cfg, frames, n, expect_found=True):
+    """run GPU + oracle on the same frames, compare every stage; returns max float differences"""
+    det = api.Detector(cfg)
+    dets, fcs = det.detect(frames, n)
+    img = det.fetch_images(n)
+    lst = det.fetch_lists(n)
+    host = frames.cpu().numpy()
+    ctx = oracle.Context(cfg)
+    by_frame = {d.frame: d for d in dets}
+    mx = dict(xy=0.0, pre_xy=0.0, rvec=0.0, tvec=0.0, rms=0.0)
+    nc = cfg.board_cols * cfg.board_rows
+    found = 0
+    for f in range(n):
+        k, odet, ofc, st = ctx.detect(host[f], f, stages=True)
+        assert (img["grey"][f] == st["grey"]).all(), "grey differs (frame %d)" % f
+        assert (img["bin"][f] == st["bin"]).all(), "threshold map differs (frame %d)" % f
+        assert img["cand_count"][f] == st["ncand"]
+        g = sorted_cands(img["cand"][f][:st["ncand"]])
+        assert (g["x"] == st["cand"]["x"]).all() and (g["y"] == st["cand"]["y"]).all() and (g["score"] == st["cand"]["score"]).all()
+        assert fcs[f].status == ofc.status and fcs[f].ncand == ofc.ncand
+        assert lst["npre"][f] == st["npre"]
+        p = lst["pre"][f][:st["npre"]]
+        assert (p["x"] == st["pre"]["x"]).all() and (p["y"] == st["pre"]["y"]).all() and (p["score"] == st["pre"]["score"]).all()
+        if st["npre"]:
+            mx["pre_xy"] = max(mx["pre_xy"], np.abs(lst["pre_xy"][f][:st["npre"]] - st["pre_xy"]).max())
+        assert fcs[f].nkept == ofc.nkept == st["nkept"]
+        kq = lst["kept"][f][:st["nkept"]]
+        assert (kq["x"] == st["kept"]["x"]).all() and (kq["y"] == st["kept"]["y"]).all()
+        assert fcs[f].ncorners == ofc.ncorners
+        if ofc.ncorners:
+            found += 1
+            assert (fc_px(fcs[f], nc) == fc_px(ofc, nc)).all(), "corner indices differ (frame %d)" % f
+            mx["xy"] = max(mx["xy"], np.abs(fc_xy(fcs[f], nc) - fc_xy(ofc, nc)).max())
+            d = by_frame[f]
+            assert d.id == odet.id and d.ncorners == odet.ncorners and d.pnp_status == odet.pnp_status
+            mx["rvec"] = max(mx["rvec"], np.abs(np.array(list(d.rvec)) - np.array(list(odet.rvec))).max())
+            mx["tvec"] = max(mx["tvec"], np.abs(np.array(list(d.tvec)) - np.array(list(odet.tvec))).max())
+            mx["rms"] = max(mx["rms"], abs(d.rms - odet.rms))
+            for c in range(4):
+                assert abs(d.corners[c][0] - odet.corners[c][0]) <= TOL and abs(d.corners[c][1] - odet.corners[c][1]) <= TOL
+        else:
+            assert f not in by_frame
+    det.close()
+    ctx.close()
+    assert mx["pre_xy"] <= TOL and mx["xy"] <= TOL and mx["rvec"] <= TOL and mx["tvec"] <= TOL, mx
+    if expect_found:
+        assert found == n, "board found in %d of %d frames" % (found, n)
+    return mx, found
+
+
+def test_pipeline_bgr_undistort(torch_cuda, oracle):
+    cfg = _make()
+    det = api.Detector(cfg)
+    frames, _ = _render(torch_cuda, det, cfg, 6)
+    det.close()
+    mx, _ = _check_batch(torch_cuda, oracle, cfg, frames, 6)
+    print("max diffs", mx)
+
+
+def test_pipeline_mono_raw_distortion_in_pnp(torch_cuda, oracle):
+    """undistort = 0: detector on the raw image, PnP with D -- the reference's own arrangement
+    (camera_pose.cpp:163 passes kdistCoeffs)"""
+    def mod(c):
+        c.undistort = 0
+    cfg = _make(mod, pixfmt=abi.RCC_PIX_MONO8)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch_cuda, det, cfg, 4, seed=77)
+    det.close()
+    mx, _ = _check_batch(torch_cuda, oracle, cfg, frames, 4, expect_found=False)
+    print("max diffs", mx)
+
+
+def test_reference_mode_truncates_corners(torch_cuda, oracle):
+    def mod(c):
+        c.reference_mode = 1
+    cfg = _make(mod, B=3)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch_cuda, det, cfg, 3, seed=5)
+    det.close()
+    _check_batch(torch_cuda, oracle, cfg, frames, 3)
+
+
+@pytest.mark.parametrize("w,h", [(645, 483), (322, 241), (64, 32), (67, 35), (131, 70)])
+def test_image_stages_ragged_noise(torch_cuda, oracle, w, h):
+    """integer stages on noise + blobs at sizes that are not multiples of the tile: bit-exact"""
+    torch = torch_cuda
+    rng = np.random.default_rng(w * 1000 + h)
+    n = 3
+    cfg = _make(w=w, h=h, pixfmt=abi.RCC_PIX_BGR8, B=n)
+    cfg.harris_thresh = 1000
+    host = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for f in range(n):  # some structure so thresholds and corners fire
+        host[f][((xx // 9 + yy // 7) % 2 == 0)] //= 4
+    frames = torch.from_numpy(host.reshape(n, -1)).cuda()
+    det = api.Detector(cfg)
+    det.detect(frames, n)
+    img = det.fetch_images(n)
+    ctx = oracle.Context(cfg)
+    for f in range(n):
+        k, odet, ofc, st = ctx.detect(host[f], f, stages=True)
+        assert (img["grey"][f] == st["grey"]).all()
+        assert (img["bin"][f] == st["bin"]).all()
+        assert img["cand_count"][f] == st["ncand"]
+        m = min(st["ncand"], cfg.max_candidates)
+        if st["ncand"] <= cfg.max_candidates:
+            g = sorted_cands(img["cand"][f][:m])
+            assert (g["x"] == st["cand"]["x"]).all() and (g["y"] == st["cand"]["y"]).all() and (g["score"] == st["cand"]["score"]).all()
+    det.close()
+
+
+def test_fisheye_ingest_bit_exact(torch_cuda, oracle):
+    """fisheye map (own atan from +,-,*,/) + remap must be bit-identical to the oracle"""
+    torch = torch_cuda
+    def mod(c):
+        abi.set_distortion(c, abi.RCC_DIST_FISHEYE, abi.FISHEYE_DEFAULT)
+    cfg = _make(mod, w=960, h=540, B=2)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch, det, cfg, 2, seed=11)
+    grey = torch.empty((2, cfg.height, cfg.width), dtype=torch.uint8, device="cuda:0")
+    det.stage_ingest(frames, 2, grey)
+    host = frames.cpu().numpy()
+    g = grey.cpu().numpy()
+    for f in range(2):
+        ref = oracle.ingest(cfg, host[f])
+        assert (g[f] == ref).all()
+    det.close()
+
+
+def test_solve_pnp_batch_matches_oracle(torch_cuda, oracle):
+    """the drop-in for camera_pose.cpp:163: 4-point tags with the reference's point layout"""
+    rng = np.random.default_rng(3)
+    cfg = _make(B=1)
+    det = api.Detector(cfg)
+    K = np.array(list(cfg.K)); D = np.array(list(cfg.D))
+    objs, imgs, gts = [], [], []
+    for t in range(300):
+        s = rng.uniform(0.03, 0.1)
+        obj = np.array([[-s, -s, 0], [s, -s, 0], [s, s, 0], [-s, s, 0]], float)   # camera_pose.cpp:158-161
+        R = synth.rodrigues([0, 0, rng.uniform(-3, 3)]) @ synth.rodrigues(np.array([np.cos(t), np.sin(t), 0]) * rng.uniform(0, 1.0)) @ np.diag([1., -1, -1])
+        rv = synth.rotmat_to_rvec(R); tv = np.array([rng.uniform(-.3, .3), rng.uniform(-.2, .2), rng.uniform(0.5, 2.5)])
+        img = synth.project_points(obj, rv, tv, K, abi.RCC_DIST_PLUMB_BOB, D)
+        if t % 2:
+            img = np.floor(img)   # the reference feeds int-truncated corners (corner_detections.cpp:53-54)
+        objs.append(obj); imgs.append(img); gts.append((rv, tv))
+    rvec, tvec, rms, status, iters = det.solve_pnp(objs, imgs, K, D, abi.RCC_DIST_PLUMB_BOB)
+    worst = 0.0
+    for t in range(300):
+        st, r, tt, e, it = oracle.solve_pnp(objs[t], imgs[t], K, abi.RCC_DIST_PLUMB_BOB, D)
+        assert st == status[t]
+        worst = max(worst, np.abs(r - rvec[t]).max(), np.abs(tt - tvec[t]).max())
+        assert abs(e - rms[t]) <= TOL
+    print("max |gpu - oracle| over 300 tag solves:", worst)
+    assert worst <= TOL
+    # Rodrigues both ways
+    Rm = det.rodrigues(rvec)
+    for t in range(0, 300, 17):
+        assert np.abs(Rm[t] - oracle.rodrigues_v2m(rvec[t])).max() <= 1e-12
+    back = det.rodrigues(Rm)
+    assert np.abs(back - rvec).max() <= 1e-9
+    det.close()
+
+
+def test_edge_cases(torch_cuda, oracle):
+    torch = torch_cuda
+    cfg = _make(B=2)
+    det = api.Detector(cfg)
+    # empty batch
+    dets, fcs = det.detect(torch.empty((0, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0"), 0)
+    assert len(dets) == 0
+    # over capacity
+    with pytest.raises(api.RccError) as e:
+        det.detect(torch.zeros((3, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0"), 3)
+    assert e.value.status == abi.RCC_ERR_CAPACITY
+    # blank frames: no candidates, no detection, no error
+    dets, fcs = det.detect(torch.full((2, cfg.frame_bytes), 128, dtype=torch.uint8, device="cuda:0"), 2)
+    assert len(dets) == 0 and fcs[0].ncand == 0 and fcs[0].status == abi.RCC_FRAME_NOT_FOUND
+    # host-resident input gives the same answer as device-resident input
+    frames, _ = _render(torch, det, cfg, 2, seed=21)
+    d1, f1 = det.detect(frames, 2)
+    d2, f2 = det.detect(frames.cpu().numpy(), 2)
+    assert len(d1) == len(d2) == 2
+    for a, b in zip(d1, d2):
+        assert list(a.rvec) == list(b.rvec) and list(a.tvec) == list(b.tvec)
+    det.close()
+    # candidate overflow is flagged, deterministically
+    cfg2 = _make(B=1)
+    cfg2.max_candidates = 16
+    det2 = api.Detector(cfg2)
+    dets, fcs = det2.detect(frames[:1], 1)
+    ctx = oracle.Context(cfg2)
+    k, odet, ofc = ctx.detect(frames[:1].cpu().numpy()[0], 0)
+    assert fcs[0].status == ofc.status == abi.RCC_FRAME_CAND_OVERFLOW and len(dets) == 0
+    det2.close()
+    # bad configuration
+    bad = _make()
+    bad.max_candidates = 0
+    with pytest.raises(api.RccError):
+        api.Detector(bad)
