@@ -252,59 +252,62 @@ void orc_threshold_tiles(const uint8_t* grey, int w, int h, int min_contrast, ui
 
 /* ------------------------------------------------------------------------------------------------
  * a4  Harris response, all-integer form [B] of SURVEY appendix B.4 (cornerHarris structure:
- * Sobel 3x3 -> structure tensor over blockSize 5 -> det - k*trace^2):
+ * Sobel 3x3 -> structure tensor over blockSize 5 -> det - k*trace^2), evaluated on the EVEN pixel
+ * lattice (x and y even):
  *   gx, gy = Sobel3x3 >> 3          (arithmetic shift; grey levels per pixel, in [-128,127])
- *   pxx = (gx*gx) >> 4, pxy = (gx*gy) >> 4, pyy = (gy*gy) >> 4      (floor)
- *   A,B,C  = 5x5 box sums of pxx,pxy,pyy                              (|.| <= 25600)
- *   R      = A*C - B*B - ((A+C)^2 >> 4)                               (k = 1/16), fits int32
- * R is defined where the 7x7 support lies inside the image; elsewhere INT32_MIN.
+ *   A = (sum_5x5 gx*gx) >> 4,  B = (sum_5x5 gx*gy) >> 4 (floor),  C = (sum_5x5 gy*gy) >> 4
+ *                                                                      (0 <= A,C <= 25600)
+ *   R = A*C - B*B - ((A+C)^2 >> 4)                                    (k = 1/16), fits int32
+ * R is defined at even (x,y) whose 7x7 support lies inside the image; elsewhere INT32_MIN.
+ * The lattice halves the response work per axis; sub-pixel refinement (a5) recovers the position.
  * ---------------------------------------------------------------------------------------------- */
 void orc_harris_response(const uint8_t* g, int w, int h, int32_t* R)
 {
   size_t n = (size_t)w * h;
-  int16_t* pxx = (int16_t*)calloc(n, sizeof(int16_t));
-  int16_t* pxy = (int16_t*)calloc(n, sizeof(int16_t));
-  int16_t* pyy = (int16_t*)calloc(n, sizeof(int16_t));
+  int8_t* gxv = (int8_t*)calloc(n, 1);
+  int8_t* gyv = (int8_t*)calloc(n, 1);
   for (size_t i = 0; i < n; ++i) R[i] = INT32_MIN;
   for (int y = 1; y < h - 1; ++y)
     for (int x = 1; x < w - 1; ++x) {
       const uint8_t* p = g + (size_t)y * w + x;
       int sx = (p[-w + 1] + 2 * p[1] + p[w + 1]) - (p[-w - 1] + 2 * p[-1] + p[w - 1]);
       int sy = (p[w - 1] + 2 * p[w] + p[w + 1]) - (p[-w - 1] + 2 * p[-w] + p[-w + 1]);
-      int gx = sx >> 3, gy = sy >> 3;
-      pxx[(size_t)y * w + x] = (int16_t)((gx * gx) >> 4);
-      pxy[(size_t)y * w + x] = (int16_t)((gx * gy) >> 4);
-      pyy[(size_t)y * w + x] = (int16_t)((gy * gy) >> 4);
+      gxv[(size_t)y * w + x] = (int8_t)(sx >> 3);
+      gyv[(size_t)y * w + x] = (int8_t)(sy >> 3);
     }
-  for (int y = 3; y < h - 3; ++y)
-    for (int x = 3; x < w - 3; ++x) {
-      int32_t A = 0, B = 0, C = 0;
+  for (int y = 4; y < h - 3; y += 2)
+    for (int x = 4; x < w - 3; x += 2) {
+      int32_t sa = 0, sb = 0, sc = 0;
       for (int dy = -2; dy <= 2; ++dy)
         for (int dx = -2; dx <= 2; ++dx) {
           size_t i = (size_t)(y + dy) * w + (x + dx);
-          A += pxx[i]; B += pxy[i]; C += pyy[i];
+          int a = gxv[i], b = gyv[i];
+          sa += a * a; sb += a * b; sc += b * b;
         }
+      int32_t A = sa >> 4, B = sb >> 4, C = sc >> 4;
       uint32_t tr = (uint32_t)(A + C);
-      int32_t r = A * C - B * B - (int32_t)((tr * tr) >> 4);
-      R[(size_t)y * w + x] = r;
+      R[(size_t)y * w + x] = A * C - B * B - (int32_t)((tr * tr) >> 4);
     }
-  free(pxx); free(pxy); free(pyy);
+  free(gxv); free(gyv);
 }
 
-/* a4 dense selection [B]: R >= thresh, strict 3x3 local maximum with scan-order tie break
- * (greater than the four neighbours that precede it in (y,x) order, not less than the four that
- * follow), at least `margin` pixels from every border.  Output sorted by (y,x). */
+/* a4 dense selection [B]: lattice points with R >= thresh that are 3x3 maxima ON THE LATTICE
+ * (neighbours at +-2 pixels) with scan-order tie break: greater than the four lattice neighbours
+ * that precede it in (y,x) order, not less than the four that follow; at least `margin` pixels
+ * from every border.  Output sorted by (y,x). */
 int orc_harris_candidates(const int32_t* R, int w, int h, int thresh, int margin, orc_cand* out, int cap)
 {
   int n = 0;
-  if (margin < 4) margin = 4;
-  for (int y = margin; y < h - margin; ++y)
-    for (int x = margin; x < w - margin; ++x) {
+  if (margin < 6) margin = 6;
+  int m0 = (margin + 1) & ~1;   /* first even coordinate >= margin */
+  for (int y = m0; y < h - margin; y += 2)
+    for (int x = m0; x < w - margin; x += 2) {
       const int32_t* p = R + (size_t)y * w + x;
+      const int w2 = 2 * w;
       int32_t r = *p;
       if (r < thresh) continue;
-      if (!(r > p[-w - 1] && r > p[-w] && r > p[-w + 1] && r > p[-1])) continue;
-      if (!(r >= p[1] && r >= p[w - 1] && r >= p[w] && r >= p[w + 1])) continue;
+      if (!(r > p[-w2 - 2] && r > p[-w2] && r > p[-w2 + 2] && r > p[-2])) continue;
+      if (!(r >= p[2] && r >= p[w2 - 2] && r >= p[w2] && r >= p[w2 + 2])) continue;
       if (n < cap) { out[n].x = (int16_t)x; out[n].y = (int16_t)y; out[n].score = r; }
       ++n;
     }

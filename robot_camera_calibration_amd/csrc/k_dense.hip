@@ -1,5 +1,6 @@
 // k_dense.hip -- the "threshold + corner pass": stages a3 (apriltag tile threshold) and a4.1
-// (integer Harris response, 3x3 maximum selection, wave-ballot compaction), fused: one read of the
+// (integer Harris response on the even pixel lattice, 3x3 lattice maximum selection, wave-ballot
+// compaction), fused: one read of the
 // grey image, one write of the threshold map, a short candidate list.
 //
 // Stands in for the per-pixel passes of the external detector (apriltag threshold(); SURVEY.md
@@ -15,11 +16,13 @@
 
 #define BW 64
 #define BH 32
-#define GR_W 80            // grey region row pitch (>= BW + 3 + 11)
-#define GR_H (BH + 3 + 11) // 46: 4-px halo each side + 3 ragged px of a last tile seen as halo
-#define PR_W (BW + 3 + 6)  // products region width  (73)
-#define PR_H (BH + 3 + 6)  // 41
-#define HS_W (BW + 3 + 2)  // hsum / R region width (69)
+#define OFF 8              // region origin = (x0-OFF, y0-OFF): halo 5 needed, 8 keeps rows dword-aligned
+#define GR_W 84            // >= BW + 3 + OFF + 7
+#define GR_H (BH + 3 + OFF + 7)
+#define GD_W (BW + 3 + 8)  // gradient region [x0-4, x1+4)
+#define GD_H (BH + 3 + 8)
+#define LT_W ((BW + 3 + 4) / 2 + 2)  // lattice columns covering [x0-2, x1+2)
+#define LT_H ((BH + 3 + 4) / 2 + 2)
 #define TL_W 18            // threshold tiles incl. halo
 #define TL_H 10
 
@@ -29,9 +32,9 @@ __global__ __launch_bounds__(256) void k_dense_lds(const uint8_t* __restrict__ g
                                                    rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count)
 {
   __shared__ uint8_t sg[GR_H][GR_W];
-  __shared__ int16_t spxx[PR_H][PR_W], spxy[PR_H][PR_W], spyy[PR_H][PR_W];
-  __shared__ int16_t shxx[PR_H][HS_W], shxy[PR_H][HS_W], shyy[PR_H][HS_W];
-  __shared__ int32_t sR[BH + 3 + 2][HS_W];
+  __shared__ int8_t sgx[GD_H][GD_W], sgy[GD_H][GD_W];
+  __shared__ int32_t shA[GD_H][LT_W], shB[GD_H][LT_W], shC[GD_H][LT_W];   // horizontal raw 5-sums at even x
+  __shared__ int32_t sR[LT_H][LT_W];
   __shared__ uint8_t stmin[TL_H][TL_W], stmax[TL_H][TL_W];
   __shared__ uint8_t sdmin[TL_H][TL_W], sdmax[TL_H][TL_W];
 
@@ -48,17 +51,17 @@ __global__ __launch_bounds__(256) void k_dense_lds(const uint8_t* __restrict__ g
   const uint8_t* g = grey + (size_t)f * w * h;
   uint8_t* bo = bin + (size_t)f * w * h;
 
-  // ---- stage 0: grey region [x0-4, x1+7) x [y0-4, y1+7), coordinates clamped to the image
-  // (+3: an extended last tile can be the right/bottom halo tile of the block before it)
-  const int rw = bw + 11, rh = bh + 11;
+  // ---- stage 0: grey region [x0-8, x1+7) x [y0-8, y1+7), coordinates clamped to the image
+  // (+7 right/bottom: 5 for the lattice halo, and an extended last tile seen as a halo tile)
+  const int rw = bw + OFF + 7, rh = bh + OFF + 7;
   for (int i = tid; i < rw * rh; i += 256) {
     int ry = i / rw, rx = i - ry * rw;
-    int gx = min(max(x0 - 4 + rx, 0), w - 1), gy = min(max(y0 - 4 + ry, 0), h - 1);
+    int gx = min(max(x0 - OFF + rx, 0), w - 1), gy = min(max(y0 - OFF + ry, 0), h - 1);
     sg[ry][rx] = g[(size_t)gy * w + gx];
   }
   __syncthreads();
 
-  // ---- stage 1: threshold-tile min/max for tiles [tx0-1, ...] (halo of one tile)
+  // ---- stage 1: threshold-tile min/max for tiles [tx0-1, ...] (halo of one tile), then 3x3 dilation
   const int tx0 = x0 >> 2, ty0 = y0 >> 2;
   const int ntx = ((bx == nbx - 1) ? tw - tx0 : BW / 4), nty = ((by == nby - 1) ? th - ty0 : BH / 4);
   for (int i = tid; i < TL_W * TL_H; i += 256) {
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void k_dense_lds(const uint8_t* __restrict__ g
       int py0 = ty * 4, py1 = (ty == th - 1) ? h : py0 + 4;
       for (int yy = py0; yy < py1; ++yy)
         for (int xx = px0; xx < px1; ++xx) {
-          int v = sg[yy - (y0 - 4)][xx - (x0 - 4)];
+          int v = sg[yy - (y0 - OFF)][xx - (x0 - OFF)];
           mn = min(mn, v);
           mx = max(mx, v);
         }
@@ -93,20 +96,18 @@ __global__ __launch_bounds__(256) void k_dense_lds(const uint8_t* __restrict__ g
     sdmax[j][k] = (uint8_t)mx;
   }
 
-  // ---- stage 2: gradients and products on [x0-3, x1+3) x [y0-3, y1+3)
-  const int pw = bw + 6, ph = bh + 6;
-  for (int i = tid; i < pw * ph; i += 256) {
-    int py = i / pw, px = i - py * pw;
-    const int ry = py + 1, rx = px + 1;   // region coordinates of this pixel
+  // ---- stage 2: gradients on [x0-4, x1+4) x [y0-4, y1+4)
+  const int dw = bw + 8, dh = bh + 8;
+  for (int i = tid; i < dw * dh; i += 256) {
+    int py = i / dw, px = i - py * dw;
+    const int ry = py + OFF - 4, rx = px + OFF - 4;   // region coordinates of this pixel
     int a00 = sg[ry - 1][rx - 1], a01 = sg[ry - 1][rx], a02 = sg[ry - 1][rx + 1];
     int a10 = sg[ry][rx - 1], a12 = sg[ry][rx + 1];
     int a20 = sg[ry + 1][rx - 1], a21 = sg[ry + 1][rx], a22 = sg[ry + 1][rx + 1];
     int sx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20);
     int sy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
-    int gx = sx >> 3, gy = sy >> 3;
-    spxx[py][px] = (int16_t)((gx * gx) >> 4);
-    spxy[py][px] = (int16_t)((gx * gy) >> 4);
-    spyy[py][px] = (int16_t)((gy * gy) >> 4);
+    sgx[py][px] = (int8_t)(sx >> 3);
+    sgy[py][px] = (int8_t)(sy >> 3);
   }
   __syncthreads();
 
@@ -116,56 +117,62 @@ __global__ __launch_bounds__(256) void k_dense_lds(const uint8_t* __restrict__ g
     int x = x0 + px, y = y0 + py;
     int k = min(x >> 2, tw - 1) - tx0 + 1, j = min(y >> 2, th - 1) - ty0 + 1;
     int mn = sdmin[j][k], mx = sdmax[j][k];
-    int v = sg[py + 4][px + 4];
+    int v = sg[py + OFF][px + OFF];
     uint8_t o = (mx - mn < min_contrast) ? (uint8_t)127 : ((v > mn + (mx - mn) / 2) ? (uint8_t)255 : (uint8_t)0);
     bo[(size_t)y * w + x] = o;
   }
 
-  // ---- stage 4: horizontal 5-sums on columns [x0-1, x1+1), rows [y0-3, y1+3)
-  const int hw = bw + 2;
-  for (int i = tid; i < hw * ph; i += 256) {
-    int py = i / hw, hx = i - py * hw;
-    int a = 0, b = 0, c = 0;
+  // ---- stage 4: horizontal raw 5-sums of products at even x in [x0-2, x1+2), all gradient rows
+  // lattice column c <-> x = x0 - 2 + 2c   (x0 is a multiple of 64, so these are even)
+  const int lw = (bw + 4 + 1) / 2, lh = (bh + 4 + 1) / 2;
+  for (int i = tid; i < lw * dh; i += 256) {
+    int py = i / lw, c = i - py * lw;
+    int gxc = 2 * c + 2;   // gradient-region column of x = x0-2+2c  (region starts at x0-4)
+    int a = 0, b = 0, cc = 0;
 #pragma unroll
-    for (int d = 0; d < 5; ++d) { a += spxx[py][hx + d]; b += spxy[py][hx + d]; c += spyy[py][hx + d]; }
-    shxx[py][hx] = (int16_t)a;
-    shxy[py][hx] = (int16_t)b;
-    shyy[py][hx] = (int16_t)c;
-  }
-  __syncthreads();
-
-  // ---- stage 5: vertical 5-sums -> response on [x0-1, x1+1) x [y0-1, y1+1)
-  const int rh2 = bh + 2;
-  for (int i = tid; i < hw * rh2; i += 256) {
-    int ry = i / hw, hx = i - ry * hw;
-    int x = x0 - 1 + hx, y = y0 - 1 + ry;
-    int32_t r = INT32_MIN;
-    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
-      int A = 0, B = 0, C = 0;
-#pragma unroll
-      for (int d = 0; d < 5; ++d) { A += shxx[ry + d][hx]; B += shxy[ry + d][hx]; C += shyy[ry + d][hx]; }
-      uint32_t tr = (uint32_t)(A + C);
-      r = A * C - B * B - (int32_t)((tr * tr) >> 4);
+    for (int d = -2; d <= 2; ++d) {
+      int u = sgx[py][gxc + d], v = sgy[py][gxc + d];
+      a += u * u; b += u * v; cc += v * v;
     }
-    sR[ry][hx] = r;
+    shA[py][c] = a; shB[py][c] = b; shC[py][c] = cc;
   }
   __syncthreads();
 
-  // ---- stage 6: 3x3 maximum selection + wave-ballot compaction
-  if (margin < 4) margin = 4;
-  const int npx = bw * bh;
+  // ---- stage 5: vertical 5-sums at even y in [y0-2, y1+2) -> response on the lattice
+  for (int i = tid; i < lw * lh; i += 256) {
+    int r = i / lw, c = i - r * lw;
+    int x = x0 - 2 + 2 * c, y = y0 - 2 + 2 * r;
+    int32_t resp = INT32_MIN;
+    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
+      int gyr = 2 * r + 2;   // gradient-region row of y
+      int sa = 0, sb = 0, sc = 0;
+#pragma unroll
+      for (int d = -2; d <= 2; ++d) { sa += shA[gyr + d][c]; sb += shB[gyr + d][c]; sc += shC[gyr + d][c]; }
+      int A = sa >> 4, B = sb >> 4, C = sc >> 4;
+      uint32_t tr = (uint32_t)(A + C);
+      resp = A * C - B * B - (int32_t)((tr * tr) >> 4);
+    }
+    sR[r][c] = resp;
+  }
+  __syncthreads();
+
+  // ---- stage 6: 3x3 maximum selection on the lattice + wave-ballot compaction
+  if (margin < 6) margin = 6;
+  const int cw = (bw + 1) / 2, ch = (bh + 1) / 2;   // lattice points inside the block
+  const int npx = cw * ch;
   for (int base = 0; base < npx; base += 256) {
     int i = base + tid;
     bool is = false;
     int x = 0, y = 0;
     int32_t r = 0;
     if (i < npx) {
-      int py = i / bw, px = i - py * bw;
-      x = x0 + px; y = y0 + py;
-      r = sR[py + 1][px + 1];
+      int pr = i / cw, pc = i - pr * cw;
+      x = x0 + 2 * pc; y = y0 + 2 * pr;
+      const int rr = pr + 1, rc = pc + 1;
+      r = sR[rr][rc];
       if (r >= hthresh && x >= margin && x < w - margin && y >= margin && y < h - margin) {
-        is = r > sR[py][px] && r > sR[py][px + 1] && r > sR[py][px + 2] && r > sR[py + 1][px] &&
-             r >= sR[py + 1][px + 2] && r >= sR[py + 2][px] && r >= sR[py + 2][px + 1] && r >= sR[py + 2][px + 2];
+        is = r > sR[rr - 1][rc - 1] && r > sR[rr - 1][rc] && r > sR[rr - 1][rc + 1] && r > sR[rr][rc - 1] &&
+             r >= sR[rr][rc + 1] && r >= sR[rr + 1][rc - 1] && r >= sR[rr + 1][rc] && r >= sR[rr + 1][rc + 1];
       }
     }
     unsigned long long m = __ballot(is);

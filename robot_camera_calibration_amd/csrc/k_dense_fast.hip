@@ -1,3 +1,228 @@
-// k_dense_fast.hip -- placeholder translation unit; the row-marching variant of the dense pass
-// is added here (see k_dense.hip for the weak defaults that report "not supported").
+// k_dense_fast.hip -- variant 1 of the threshold + corner pass (a3 + a4.1): row marching.
+//
+// Same definitions and bit-exact same outputs as k_dense_lds (k_dense.hip); needs width % 4 == 0
+// and height % 4 == 0 (every BASELINE.json geometry).  Mapping for gfx950:
+//   * one wavefront = one vertical strip: 64 lanes x 4 pixels (one dword of the grey row per lane,
+//     a 256 B coalesced load per row), lanes 0,1 and 63 are halo => 244 useful pixels;
+//   * the wave marches down the rows of its segment; every stencil stage keeps its state in
+//     registers (Sobel partials of 3 rows, structure-tensor row sums of 5 rows folded into pair
+//     sums, 3 lattice rows of the response, 3 tile rows of threshold statistics) -- no LDS;
+//   * neighbouring lanes exchange edge values with whole-wave DPP shifts (wave_shr / wave_shl);
+//   * 16-bit packed arithmetic (v_pk_*) for the Sobel stage and the threshold, v_dot2_i32_i16 for
+//     the products + horizontal sums of the structure tensor;
+//   * candidates leave through one ballot + one atomic per wave.
+// HBM traffic = the algorithmic 2 B/px plus halo re-reads (8/248 per row, mostly L2 hits) plus two
+// warm-up tile rows per segment.
 #include "rcc_internal.h"
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+#define DPP_FROM_LEFT 0x138   // wave_shr:1 : lane l reads lane l-1
+#define DPP_FROM_RIGHT 0x130  // wave_shl:1 : lane l reads lane l+1
+
+__device__ __forceinline__ int from_left(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, DPP_FROM_LEFT, 0xf, 0xf, false); }
+__device__ __forceinline__ int from_right(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, DPP_FROM_RIGHT, 0xf, 0xf, false); }
+__device__ __forceinline__ i16x2 as_i(unsigned v) { return __builtin_bit_cast(i16x2, v); }
+__device__ __forceinline__ u16x2 as_u(unsigned v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ unsigned bits(i16x2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ unsigned bits(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+struct HSum { int xx0, xy0, yy0, xx2, xy2, yy2; };   // raw 5-px row sums at pixel 0 and pixel 2 of the lane
+
+// ---- job geometry ----------------------------------------------------------------------------------
+#define STRIP_USE 244   // useful pixels per wave strip: lanes 2..62 (the left lattice neighbour of the
+                        // first useful pixel needs a 5-pixel halo => two halo lanes on the left, one on the right)
+
+__global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__ grey, int w, int h,
+                                                     int nstrips, int nseg, int seg_tiles, int nframes,
+                                                     int min_contrast, int hthresh, int margin, int cap,
+                                                     uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand,
+                                                     int32_t* __restrict__ cand_count)
+{
+  const int lane = threadIdx.x & 63;
+  const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int njobs = nstrips * nseg * nframes;
+  if (job >= njobs) return;
+  const int strip = job % nstrips;
+  const int seg = (job / nstrips) % nseg;
+  const int f = job / (nstrips * nseg);
+  const int th = h >> 2;
+  const int t0 = seg * seg_tiles;
+  const int t1 = min(t0 + seg_tiles, th);
+  const int xs = strip * STRIP_USE - 8;
+  const int x0 = xs + 4 * lane;                         // first pixel of this lane
+  const int xl = min(max(x0, 0), w - 4);                // clamped load column
+  const bool lane_out = (lane >= 2) && (lane <= 62) && (x0 >= 0) && (x0 < w);
+  const uint8_t* g = grey + (size_t)f * w * h + xl;
+  uint8_t* bo = bin + (size_t)f * w * h + x0;
+  if (margin < 6) margin = 6;
+
+  // pipeline state
+  i16x2 dh01_a = 0, dh23_a = 0, sh01_a = 0, sh23_a = 0;   // row r-2
+  i16x2 dh01_b = 0, dh23_b = 0, sh01_b = 0, sh23_b = 0;   // row r-1
+  HSum hprev = { 0, 0, 0, 0, 0, 0 }, pa = { 0, 0, 0, 0, 0, 0 }, pb = { 0, 0, 0, 0, 0, 0 };
+  int rm0 = INT32_MIN, rm2 = INT32_MIN, rmL = INT32_MIN, rmR = INT32_MIN;   // lattice row y-4
+  int rc0 = INT32_MIN, rc2 = INT32_MIN, rcL = INT32_MIN, rcR = INT32_MIN;   // lattice row y-2
+  int hmin_a = 255, hmax_a = 0, hmin_b = 255, hmax_b = 0;                  // tile rows t-2, t-1 (horizontally dilated)
+  unsigned gp0 = 0, gp1 = 0, gp2 = 0, gp3 = 0;                              // grey of tile row t-1
+
+  auto load_row = [&](int r) -> unsigned {
+    int rr = min(max(r, 0), h - 1);
+    return *reinterpret_cast<const unsigned*>(g + (size_t)rr * w);
+  };
+
+  int t = t0 - 2;
+  unsigned gc0 = load_row(4 * t), gc1 = load_row(4 * t + 1), gc2 = load_row(4 * t + 2), gc3 = load_row(4 * t + 3);
+
+  for (; t <= t1; ++t) {
+    // prefetch the next tile row
+    unsigned gn0 = load_row(4 * t + 4), gn1 = load_row(4 * t + 5), gn2 = load_row(4 * t + 6), gn3 = load_row(4 * t + 7);
+    u16x2 tmn = (u16x2)(255), tmx = (u16x2)(0);
+
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned G = (k == 0) ? gc0 : (k == 1) ? gc1 : (k == 2) ? gc2 : gc3;
+      const int r = 4 * t + k;
+      // ---- stage A (row r): horizontal Sobel partials, natural-order pixel pairs
+      const unsigned GL = (unsigned)from_left((int)G, (int)G), GR = (unsigned)from_right((int)G, (int)G);
+      const u16x2 n0 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));    // [p0,p1]
+      const u16x2 n1 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C030C02u));    // [p2,p3]
+      const u16x2 mm = as_u(__builtin_amdgcn_perm(0u, G, 0x0C020C01u));    // [p1,p2]
+      const u16x2 lh = as_u(__builtin_amdgcn_perm(GL, G, 0x0C000C07u));    // [p-1,p0]
+      const u16x2 rh = as_u(__builtin_amdgcn_perm(GR, G, 0x0C040C03u));    // [p3,p4]
+      tmn = __builtin_elementwise_min(tmn, __builtin_elementwise_min(n0, n1));
+      tmx = __builtin_elementwise_max(tmx, __builtin_elementwise_max(n0, n1));
+      const i16x2 dh01 = as_i(bits(mm)) - as_i(bits(lh));                 // I[x+1]-I[x-1] for x = p0,p1
+      const i16x2 dh23 = as_i(bits(rh)) - as_i(bits(mm));
+      const i16x2 sh01 = as_i(bits(lh)) + as_i(bits(n0)) + as_i(bits(n0)) + as_i(bits(mm));   // I[x-1]+2I[x]+I[x+1]
+      const i16x2 sh23 = as_i(bits(mm)) + as_i(bits(n1)) + as_i(bits(n1)) + as_i(bits(rh));
+      // ---- stage B (row rho = r-1): gradients
+      const i16x2 gx01 = (dh01_a + dh01_b + dh01_b + dh01) >> 3;
+      const i16x2 gx23 = (dh23_a + dh23_b + dh23_b + dh23) >> 3;
+      const i16x2 gy01 = (sh01 - sh01_a) >> 3;
+      const i16x2 gy23 = (sh23 - sh23_a) >> 3;
+      dh01_a = dh01_b; dh23_a = dh23_b; sh01_a = sh01_b; sh23_a = sh23_b;
+      dh01_b = dh01; dh23_b = dh23; sh01_b = sh01; sh23_b = sh23;
+      // ---- stage C (row rho): products + horizontal 5-sums at pixels 0 and 2
+      const int d0xx = __builtin_amdgcn_sdot2(gx01, gx01, 0, false);
+      const int d0xy = __builtin_amdgcn_sdot2(gx01, gy01, 0, false);
+      const int d0yy = __builtin_amdgcn_sdot2(gy01, gy01, 0, false);
+      const int d1xx = __builtin_amdgcn_sdot2(gx23, gx23, 0, false);
+      const int d1xy = __builtin_amdgcn_sdot2(gx23, gy23, 0, false);
+      const int d1yy = __builtin_amdgcn_sdot2(gy23, gy23, 0, false);
+      const int ax0 = gx01.x, ay0 = gy01.x, ax2 = gx23.x, ay2 = gy23.x;
+      const int q0xx = __mul24(ax0, ax0), q0xy = __mul24(ax0, ay0), q0yy = __mul24(ay0, ay0);
+      const int q2xx = __mul24(ax2, ax2), q2xy = __mul24(ax2, ay2), q2yy = __mul24(ay2, ay2);
+      HSum hc;
+      hc.xx0 = d0xx + q2xx + from_left(d1xx, 0);
+      hc.xy0 = d0xy + q2xy + from_left(d1xy, 0);
+      hc.yy0 = d0yy + q2yy + from_left(d1yy, 0);
+      hc.xx2 = d0xx + d1xx + from_right(q0xx, 0);
+      hc.xy2 = d0xy + d1xy + from_right(q0xy, 0);
+      hc.yy2 = d0yy + d1yy + from_right(q0yy, 0);
+      // ---- stage D/E/F: vertical sums on the lattice, response, selection
+      if ((k & 1) == 0) {
+        // rho = r-1 is odd: close the pair (rho-1, rho)
+        pa = pb;
+        pb.xx0 = hprev.xx0 + hc.xx0; pb.xy0 = hprev.xy0 + hc.xy0; pb.yy0 = hprev.yy0 + hc.yy0;
+        pb.xx2 = hprev.xx2 + hc.xx2; pb.xy2 = hprev.xy2 + hc.xy2; pb.yy2 = hprev.yy2 + hc.yy2;
+      } else {
+        // rho = r-1 is even: 5-row sums centred on y = rho-2, response there
+        const int A0 = (pa.xx0 + pb.xx0 + hc.xx0) >> 4, B0 = (pa.xy0 + pb.xy0 + hc.xy0) >> 4, C0 = (pa.yy0 + pb.yy0 + hc.yy0) >> 4;
+        const int A2 = (pa.xx2 + pb.xx2 + hc.xx2) >> 4, B2 = (pa.xy2 + pb.xy2 + hc.xy2) >> 4, C2 = (pa.yy2 + pb.yy2 + hc.yy2) >> 4;
+        const unsigned tr0 = (unsigned)(A0 + C0), tr2 = (unsigned)(A2 + C2);
+        const int rn0 = __mul24(A0, C0) - __mul24(B0, B0) - (int)(__umul24(tr0, tr0) >> 4);
+        const int rn2 = __mul24(A2, C2) - __mul24(B2, B2) - (int)(__umul24(tr2, tr2) >> 4);
+        const int rnL = from_left(rn2, INT32_MIN), rnR = from_right(rn0, INT32_MIN);
+        hprev = hc;
+        // selection on lattice row yc = rho - 4 = r - 5 (rows rm = yc-2, rc = yc, rn = yc+2)
+        const int yc = r - 5;
+        const bool rowok = (yc >= 4 * t0) && (yc < 4 * t1) && (yc >= margin) && (yc < h - margin);
+        if (rowok && __any((rc0 >= hthresh) || (rc2 >= hthresh))) {
+          const int xa = x0, xb = x0 + 2;
+          bool is0 = lane_out && rc0 >= hthresh && xa >= margin && xa < w - margin &&
+                     rc0 > rmL && rc0 > rm0 && rc0 > rm2 && rc0 > rcL &&
+                     rc0 >= rc2 && rc0 >= rnL && rc0 >= rn0 && rc0 >= rn2;
+          bool is2 = lane_out && rc2 >= hthresh && xb >= margin && xb < w - margin &&
+                     rc2 > rm0 && rc2 > rm2 && rc2 > rmR && rc2 > rc0 &&
+                     rc2 >= rcR && rc2 >= rn0 && rc2 >= rn2 && rc2 >= rnR;
+          const unsigned long long m0 = __ballot(is0), m2 = __ballot(is2);
+          const int n0c = __popcll(m0), n2c = __popcll(m2);
+          if (n0c + n2c) {
+            int basei = 0;
+            if (lane == 0) basei = atomicAdd(&cand_count[f], n0c + n2c);
+            basei = __shfl(basei, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (is0) {
+              int idx = basei + __popcll(m0 & below);
+              if (idx < cap) { rcc_cand e; e.x = (int16_t)xa; e.y = (int16_t)yc; e.score = rc0; cand[(size_t)f * cap + idx] = e; }
+            }
+            if (is2) {
+              int idx = basei + n0c + __popcll(m2 & below);
+              if (idx < cap) { rcc_cand e; e.x = (int16_t)xb; e.y = (int16_t)yc; e.score = rc2; cand[(size_t)f * cap + idx] = e; }
+            }
+          }
+        }
+        rm0 = rc0; rm2 = rc2; rmL = rcL; rmR = rcR;
+        rc0 = rn0; rc2 = rn2; rcL = rnL; rcR = rnR;
+      }
+    }
+
+    // ---- stage G: threshold.  Statistics of tile row t, then output of tile row t-1.
+    int tmin = min((int)tmn.x, (int)tmn.y), tmax = max((int)tmx.x, (int)tmx.y);
+    int hmin = min(tmin, min(from_left(tmin, tmin), from_right(tmin, tmin)));
+    int hmax = max(tmax, max(from_left(tmax, tmax), from_right(tmax, tmax)));
+    {
+      const int dmin = min(hmin_a, min(hmin_b, hmin)), dmax = max(hmax_a, max(hmax_b, hmax));
+      const int range = dmax - dmin;
+      const int thr = dmin + (range >> 1);
+      const bool flat = range < min_contrast;
+      const int tt = t - 1;
+      if (tt >= t0 && tt < t1 && lane_out) {
+        const u16x2 thr2 = (u16x2)((unsigned short)thr);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned G = (k == 0) ? gp0 : (k == 1) ? gp1 : (k == 2) ? gp2 : gp3;
+          const u16x2 a = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));
+          const u16x2 b = as_u(__builtin_amdgcn_perm(0u, G, 0x0C030C02u));
+          // v > thr ? 255 : 0 per 16-bit half: saturating (v - thr), clamp to 1, times 255
+          u16x2 da = __builtin_elementwise_sub_sat(a, thr2), db = __builtin_elementwise_sub_sat(b, thr2);
+          da = __builtin_elementwise_min(da, (u16x2)(1)) * (u16x2)(255);
+          db = __builtin_elementwise_min(db, (u16x2)(1)) * (u16x2)(255);
+          unsigned o = __builtin_amdgcn_perm(bits(db), bits(da), 0x06040200u);   // bytes [a.lo, a.hi, b.lo, b.hi]
+          if (flat) o = 0x7F7F7F7Fu;
+          *reinterpret_cast<unsigned*>(bo + (size_t)(4 * tt + k) * w) = o;
+        }
+      }
+    }
+    hmin_a = hmin_b; hmax_a = hmax_b; hmin_b = hmin; hmax_b = hmax;
+    gp0 = gc0; gp1 = gc1; gp2 = gc2; gp3 = gc3;
+    gc0 = gn0; gc1 = gn1; gc2 = gn2; gc3 = gn3;
+  }
+}
+
+bool rcc_dense_fast_supported(const rcc_handle* h)
+{
+  const rcc_config& c = h->cfg;
+  return (c.width % 4 == 0) && (c.height % 4 == 0) && c.width >= 8 && c.height >= 8;
+}
+
+hipError_t rcc_launch_dense_fast(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
+                                 rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s)
+{
+  const rcc_config& c = h->cfg;
+  const int w = c.width, ht = c.height, th = ht >> 2;
+  const int nstrips = (w + STRIP_USE - 1) / STRIP_USE;
+  // segments: enough jobs to fill the chip (>= ~8 waves per SIMD in flight), but at least 8 tile
+  // rows per segment so the 3 warm-up tile rows stay a small fraction
+  int seg_tiles = th;
+  const long long want = 256LL * 4 * 8;
+  while (seg_tiles > 8 && (long long)nstrips * nframes * ((th + seg_tiles - 1) / seg_tiles) < want) seg_tiles = (seg_tiles + 1) / 2;
+  const int nseg = (th + seg_tiles - 1) / seg_tiles;
+  const long long njobs = (long long)nstrips * nseg * nframes;
+  const int blocks = (int)((njobs + 3) / 4);
+  hipLaunchKernelGGL(k_dense_march, dim3(blocks), dim3(256), 0, s, d_grey, w, ht, nstrips, nseg, seg_tiles, nframes,
+                     c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, d_bin, d_cand, d_cand_count);
+  return hipGetLastError();
+}
