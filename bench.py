@@ -159,7 +159,7 @@ def main():
         S = min(a.cpu_sample, B)
         host = frames[:S].cpu().numpy()
         dets, fcs = det.detect(frames[:S].contiguous(), S, want_corners=True)
-        by = {d.frame: d for d in dets}
+        by = {int(d.frame): d for d in dets}
         T = max(1, min(os.cpu_count() or 1, 16, S))
         ctxs = [orc_py.Context(cfg) for _ in range(T)]
         parts = [list(range(t, S, T)) for t in range(T)]

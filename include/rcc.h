@@ -199,6 +199,9 @@ int rcc_stage_threshold_corner(rcc_handle* h, const void* d_grey, int32_t nframe
  * (needs width % 64 == 0); -1 = automatic.  Returns the previous value. */
 int rcc_set_dense_variant(rcc_handle* h, int variant);
 int rcc_set_ingest_variant(rcc_handle* h, int variant);
+/* PnP mapping: 0 = one lane per target, 1 = one wavefront per target when a target has more than
+ * 8 points, -1 = automatic (same as 1). */
+int rcc_set_pnp_variant(rcc_handle* h, int variant);
 /* a4 list stage + a5 + a6 + a7 for the board: consumes the dense pass outputs, fills per-frame
  * device records (layout = rcc_frame_corners / rcc_detection), then copies to host. */
 int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, const void* d_cand,

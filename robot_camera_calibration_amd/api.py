@@ -30,7 +30,9 @@ class RccError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, _LIBNAME)
+    """RCC_LIBRARY overrides the in-tree build (A/B of two builds of the same source); it must
+    still be a build of this package's csrc/ -- there is no other implementation to point it at."""
+    return os.environ.get("RCC_LIBRARY") or os.path.join(_HERE, _LIBNAME)
 
 
 def load_library():
@@ -64,6 +66,8 @@ def load_library():
     L.rcc_stage_targets.argtypes = [P, P, P, P, P, I, P, C.POINTER(I), P, P]
     L.rcc_set_dense_variant.argtypes = [P, C.c_int]
     L.rcc_set_ingest_variant.argtypes = [P, C.c_int]
+    L.rcc_set_pnp_variant.argtypes = [P, C.c_int]
+    L.rcc_set_pnp_variant.restype = C.c_int
     L.rcc_last_timings.argtypes = [P, P, I]
     L.rcc_time_dense.argtypes = [P, P, I, P, P, P, I, C.POINTER(C.c_float)]
     L.rcc_time_ingest.argtypes = [P, P, I, P, I, C.POINTER(C.c_float)]
@@ -86,7 +90,7 @@ EXPORTED_SYMBOLS = (
     "rcc_default_config", "rcc_create", "rcc_destroy", "rcc_status_string", "rcc_last_device_error",
     "rcc_abi_version", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
     "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_set_dense_variant",
-    "rcc_set_ingest_variant", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
+    "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
     "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch",
 )
 
@@ -123,6 +127,13 @@ def _is_device(x):
 
 
 CAND_DT = np.dtype([("x", np.int16), ("y", np.int16), ("score", np.int32)])
+# numpy mirrors of the result records (same layout as abi.rcc_detection / abi.rcc_frame_corners)
+DET_DT = np.dtype([("frame", "<i4"), ("id", "<i4"), ("hamming", "<i4"), ("ncorners", "<i4"), ("size", "<f8"),
+                   ("corners", "<f8", (4, 2)), ("rvec", "<f8", (3,)), ("tvec", "<f8", (3,)), ("rms", "<f8"),
+                   ("pnp_status", "<i4"), ("pnp_iters", "<i4")])
+FC_DT = np.dtype([("status", "<i4"), ("ncand", "<i4"), ("nkept", "<i4"), ("ncorners", "<i4"),
+                  ("px", "<i4", (abi.RCC_MAX_BOARD_CORNERS, 2)), ("xy", "<f8", (abi.RCC_MAX_BOARD_CORNERS, 2))])
+assert DET_DT.itemsize == C.sizeof(abi.rcc_detection) and FC_DT.itemsize == C.sizeof(abi.rcc_frame_corners)
 
 
 class Detector:
@@ -161,20 +172,21 @@ class Detector:
     # ---- the hot path -------------------------------------------------------------------------
     def detect(self, frames, nframes=None, want_corners=True, stream=None):
         """frames: numpy uint8 array (host) or torch uint8 tensor (host or device), nframes images
-        frame_bytes apart.  Returns (detections, frame_corners): ctypes arrays of rcc_detection
-        (length ndet) and rcc_frame_corners (length nframes, or None)."""
+        frame_bytes apart.  Returns (detections, frame_corners): numpy record arrays with the
+        layouts of rcc_detection (length ndet) and rcc_frame_corners (length nframes, or None);
+        fields are read as attributes (d.id, d.size, d.corners, d.rvec ...)."""
         if nframes is None:
             nframes = int(frames.shape[0])
         mem = abi.RCC_MEM_DEVICE if _is_device(frames) else abi.RCC_MEM_HOST
         if mem == abi.RCC_MEM_HOST and isinstance(frames, np.ndarray):
             frames = np.ascontiguousarray(frames)
-        det = (abi.rcc_detection * max(nframes * self.cfg.max_targets, 1))()
-        fc = (abi.rcc_frame_corners * max(nframes, 1))() if want_corners else None
+        det = np.zeros(max(nframes * self.cfg.max_targets, 1), DET_DT)
+        fc = np.zeros(max(nframes, 1), FC_DT) if want_corners else None
         ndet = C.c_int32(0)
-        st = self._L.rcc_detect_batch(self._h, _ptr(frames), nframes, mem, det, C.byref(ndet),
-                                      fc if fc is not None else None, _ptr(stream))
+        st = self._L.rcc_detect_batch(self._h, _ptr(frames), nframes, mem, _ptr(det), C.byref(ndet),
+                                      _ptr(fc), _ptr(stream))
         self._chk(st, "rcc_detect_batch")
-        return det[:ndet.value], (fc[:nframes] if fc is not None else None)
+        return det[:ndet.value].view(np.recarray), (fc[:nframes].view(np.recarray) if fc is not None else None)
 
     def solve_pnp(self, obj_pts, img_pts, K=None, D=None, dist_model=None):
         """Batched cv::solvePnP(obj, img, K, D, rvec, tvec, false, CV_ITERATIVE)
@@ -220,16 +232,19 @@ class Detector:
                                                      _ptr(d_count), _ptr(stream)), "rcc_stage_threshold_corner")
 
     def stage_targets(self, d_grey, d_bin, d_cand, d_count, nframes, want_corners=True, stream=None):
-        det = (abi.rcc_detection * max(nframes * self.cfg.max_targets, 1))()
-        fc = (abi.rcc_frame_corners * max(nframes, 1))() if want_corners else None
+        det = np.zeros(max(nframes * self.cfg.max_targets, 1), DET_DT)
+        fc = np.zeros(max(nframes, 1), FC_DT) if want_corners else None
         ndet = C.c_int32(0)
         st = self._L.rcc_stage_targets(self._h, _ptr(d_grey), _ptr(d_bin), _ptr(d_cand), _ptr(d_count), nframes,
-                                       det, C.byref(ndet), fc if fc is not None else None, _ptr(stream))
+                                       _ptr(det), C.byref(ndet), _ptr(fc), _ptr(stream))
         self._chk(st, "rcc_stage_targets")
-        return det[:ndet.value], (fc[:nframes] if fc is not None else None)
+        return det[:ndet.value].view(np.recarray), (fc[:nframes].view(np.recarray) if fc is not None else None)
 
     def set_dense_variant(self, v):
         return self._L.rcc_set_dense_variant(self._h, int(v))
+
+    def set_pnp_variant(self, v):
+        return self._L.rcc_set_pnp_variant(self._h, int(v))
 
     def set_ingest_variant(self, v):
         return self._L.rcc_set_ingest_variant(self._h, int(v))
@@ -279,9 +294,10 @@ def detections_to_dicts(dets):
     (corner_detections.cpp:48-54): id, size, pixel_corners_x/y (bl,br,tr,tl) + pose."""
     out = []
     for d in dets:
-        out.append(dict(frame=d.frame, id=d.id, size=d.size,
-                        pixel_corners_x=[d.corners[k][0] for k in range(4)],
-                        pixel_corners_y=[d.corners[k][1] for k in range(4)],
-                        rvec=list(d.rvec), tvec=list(d.tvec), rms=d.rms,
-                        pnp_status=d.pnp_status, pnp_iters=d.pnp_iters, ncorners=d.ncorners, hamming=d.hamming))
+        out.append(dict(frame=int(d.frame), id=int(d.id), size=float(d.size),
+                        pixel_corners_x=[float(d.corners[k][0]) for k in range(4)],
+                        pixel_corners_y=[float(d.corners[k][1]) for k in range(4)],
+                        rvec=[float(v) for v in d.rvec], tvec=[float(v) for v in d.tvec], rms=float(d.rms),
+                        pnp_status=int(d.pnp_status), pnp_iters=int(d.pnp_iters), ncorners=int(d.ncorners),
+                        hamming=int(d.hamming)))
     return out

@@ -3,11 +3,20 @@
 // Drop-in target: cv::solvePnP(...) at real_preprocessing/src/camera_pose.cpp:163 and
 // cv::Rodrigues at :164 (and :93,:116; opt_visualization.cpp:36).  Arithmetic in pnp_core.h.
 //
-// Mapping: one lane per target.  A 4-point fiducial solve is ~1e5 dependent fp64 operations with
-// 6x6/9x9 eigen-decompositions in the middle; it does not vectorise across points, so targets are
-// the parallel axis: 64 targets per wavefront, thousands of targets per batch.  The result record
-// layout is the C ABI's rcc_detection (what corner_detections.cpp:46-56 reads, plus the pose).
+// Two mappings, chosen by point count:
+//   * few points (a 4-corner fiducial, camera_pose.cpp:152-161): one LANE per target.  The solve is
+//     a chain of dependent fp64 operations with small factorizations in the middle and nothing to
+//     spread over 4 points, so targets are the parallel axis (64 per wavefront).
+//   * many points (the 48-corner board): one WAVEFRONT per target.  Lanes take the points; every
+//     per-point accumulation (DLT 9x9, homography refinement 8x8, pose JtJ 6x6 / Jte) is a lane-local
+//     partial sum + xor-butterfly, after which all lanes hold the same normal equations and run the
+//     small dense algebra redundantly (wave-uniform, no divergence, no LDS).
+// The result record layout is the C ABI's rcc_detection (what corner_detections.cpp:46-56 reads,
+// plus the pose).
 #include "rcc_internal.h"
+// hipcc -O3 (ROCm 7.2) miscompiles the fully inlined solver: wrong poses, and -O2 never terminates
+// (measured on MI355X; -O1, the host build and this out-of-line form all match the oracle to 1e-15).
+#define RCC_PNP_NOINLINE 1
 #include "pnp_core.h"
 
 static __device__ __forceinline__ rccpnp::Cam to_cam(const rcc_cam& c)
@@ -15,6 +24,7 @@ static __device__ __forceinline__ rccpnp::Cam to_cam(const rcc_cam& c)
   rccpnp::Cam k;
   k.fx = c.fx; k.fy = c.fy; k.cx = c.cx; k.cy = c.cy;
   for (int i = 0; i < 5; ++i) k.k[i] = c.D[i];
+  k.solver = c.solver;
   return k;
 }
 
@@ -29,7 +39,7 @@ __global__ __launch_bounds__(64) void k_pnp_generic(const double* __restrict__ o
   rccpnp::Pts p{ obj + 3 * (size_t)off[t], img + 2 * (size_t)off[t], npts[t] };
   double r[3], tv[3], e = 0.0;
   int it = 0;
-  int st = rccpnp::solve_pnp(p, to_cam(cam), cam.model, r, tv, &e, &it);
+  int st = rccpnp::solve_pnp(rccpnp::SerialPar(), p, to_cam(cam), cam.model, r, tv, &e, &it);
   for (int k = 0; k < 3; ++k) { rvec[3 * t + k] = r[k]; tvec[3 * t + k] = tv[k]; }
   if (rms) rms[t] = e;
   if (status) status[t] = st;
@@ -65,10 +75,104 @@ __global__ __launch_bounds__(64) void k_pnp_board(const rcc_frame_corners* __res
   const int idx[4] = { (rows - 1) * cols, (rows - 1) * cols + cols - 1, cols - 1, 0 };   // bl, br, tr, tl
   for (int k = 0; k < 4; ++k) { d.corners[k][0] = c->xy[idx[k]][0]; d.corners[k][1] = c->xy[idx[k]][1]; }
   int it = 0;
-  d.pnp_status = rccpnp::solve_pnp(p, to_cam(cam), cam.model, d.rvec, d.tvec, &d.rms, &it);
+  d.pnp_status = rccpnp::solve_pnp(rccpnp::SerialPar(), p, to_cam(cam), cam.model, d.rvec, d.tvec, &d.rms, &it);
   d.pnp_iters = it;
   det[f] = d;
   ndet[f] = 1;
+}
+
+// one wavefront per frame
+__global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* __restrict__ fc, int nframes,
+                                                       const double* __restrict__ board_obj, int cols, int rows,
+                                                       double square, int board_id, int reference_mode,
+                                                       rcc_cam cam, double* __restrict__ img_scratch,
+                                                       rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
+{
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x;
+  const rcc_frame_corners* c = fc + f;
+  const int need = cols * rows;
+  if (c->status != 0 || c->ncorners != need) { if (lane == 0) ndet[f] = 0; return; }
+  double* img = img_scratch + (size_t)f * 2 * RCC_MAX_BOARD_CORNERS;
+  for (int k = lane; k < need; k += 64) {
+    double x = c->xy[k][0], y = c->xy[k][1];
+    if (reference_mode) { x = (double)(int)x; y = (double)(int)y; }   // corner_detections.cpp:53-54
+    img[2 * k] = x;
+    img[2 * k + 1] = y;
+  }
+  __syncthreads();
+  rccpnp::Pts p{ board_obj, img, need };
+  rccpnp::WavePar par{ lane };
+  double r[3], tv[3], e = 0.0;
+  int it = 0;
+  const int st = rccpnp::solve_pnp(par, p, to_cam(cam), cam.model, r, tv, &e, &it);
+  if (lane == 0) {
+    rcc_detection d;
+    d.frame = f;
+    d.id = board_id;
+    d.hamming = 0;
+    d.ncorners = need;
+    d.size = square;
+    const int idx[4] = { (rows - 1) * cols, (rows - 1) * cols + cols - 1, cols - 1, 0 };   // bl, br, tr, tl
+    for (int k = 0; k < 4; ++k) { d.corners[k][0] = c->xy[idx[k]][0]; d.corners[k][1] = c->xy[idx[k]][1]; }
+    for (int k = 0; k < 3; ++k) { d.rvec[k] = r[k]; d.tvec[k] = tv[k]; }
+    d.rms = e;
+    d.pnp_status = st;
+    d.pnp_iters = it;
+    det[f] = d;
+    ndet[f] = 1;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_pnp_generic_wave(const double* __restrict__ obj, const double* __restrict__ img,
+                                                         const int32_t* __restrict__ off, const int32_t* __restrict__ npts,
+                                                         int ntargets, rcc_cam cam, double* __restrict__ rvec,
+                                                         double* __restrict__ tvec, double* __restrict__ rms,
+                                                         int32_t* __restrict__ status, int32_t* __restrict__ iters)
+{
+  const int t = blockIdx.x;
+  const int lane = threadIdx.x;
+  rccpnp::Pts p{ obj + 3 * (size_t)off[t], img + 2 * (size_t)off[t], npts[t] };
+  rccpnp::WavePar par{ lane };
+  double r[3], tv[3], e = 0.0;
+  int it = 0;
+  int st = rccpnp::solve_pnp(par, p, to_cam(cam), cam.model, r, tv, &e, &it);
+  if (lane == 0) {
+    for (int k = 0; k < 3; ++k) { rvec[3 * t + k] = r[k]; tvec[3 * t + k] = tv[k]; }
+    if (rms) rms[t] = e;
+    if (status) status[t] = st;
+    if (iters) iters[t] = it;
+  }
+}
+
+// test tap: intermediates of one solve, one thread.  out = H[9], prm_init[6], A[36], g[6], S, status
+__global__ void k_pnp_probe(const double* obj, const double* img, int n, rcc_cam cam, double* out)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  rccpnp::Pts p{ obj, img, n };
+  rccpnp::Cam cm = to_cam(cam);
+  const bool has_dist = cam.model == RCC_DIST_PLUMB_BOB;
+  if (!has_dist) for (int i = 0; i < 5; ++i) cm.k[i] = 0.0;
+  rccpnp::SerialPar par;
+  double Rt[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, Tt[3] = { 0, 0, 0 };
+  double H[9];
+  int ok = rccpnp::find_homography(par, p, Rt, Tt, cm, has_dist, H);
+  for (int i = 0; i < 9; ++i) out[i] = H[i];
+  double prm[6];
+  int st = rccpnp::pose_init(par, p, cm, has_dist, prm);
+  for (int i = 0; i < 6; ++i) out[9 + i] = prm[i];
+  double A[36], g[6];
+  double S = rccpnp::pose_accumulate(par, prm, p, cm, A, g);
+  for (int i = 0; i < 36; ++i) out[15 + i] = A[i];
+  for (int i = 0; i < 6; ++i) out[51 + i] = g[i];
+  out[57] = S;
+  out[58] = (double)(st * 10 + ok);
+}
+
+hipError_t rcc_launch_pnp_probe(const double* d_obj, const double* d_img, int n, rcc_cam cam, double* d_out, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pnp_probe, dim3(1), dim3(64), 0, s, d_obj, d_img, n, cam, d_out);
+  return hipGetLastError();
 }
 
 __global__ void k_rodrigues(int dir, const double* __restrict__ in, int n, double* __restrict__ out)
@@ -93,8 +197,12 @@ hipError_t rcc_launch_pnp_generic(rcc_handle* h, const double* d_obj, const doub
                                   int32_t* d_status, int32_t* d_iters, hipStream_t s)
 {
   if (ntargets <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_pnp_generic, dim3((ntargets + 63) / 64), dim3(64), 0, s, d_obj, d_img, d_off, d_npts,
-                     ntargets, cam, d_rvec, d_tvec, d_rms, d_status, d_iters);
+  if (h->pnp_wave_hint)   // many points per target: one wavefront each
+    hipLaunchKernelGGL(k_pnp_generic_wave, dim3(ntargets), dim3(64), 0, s, d_obj, d_img, d_off, d_npts,
+                       ntargets, cam, d_rvec, d_tvec, d_rms, d_status, d_iters);
+  else
+    hipLaunchKernelGGL(k_pnp_generic, dim3((ntargets + 63) / 64), dim3(64), 0, s, d_obj, d_img, d_off, d_npts,
+                       ntargets, cam, d_rvec, d_tvec, d_rms, d_status, d_iters);
   return hipGetLastError();
 }
 
@@ -106,9 +214,15 @@ hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s)
   cam.fx = c.K[0]; cam.cx = c.K[2]; cam.fy = c.K[4]; cam.cy = c.K[5];
   for (int i = 0; i < 8; ++i) cam.D[i] = c.D[i];
   cam.model = h->undist ? RCC_DIST_NONE : c.dist_model;   // undistorted image: solve with D = 0
-  hipLaunchKernelGGL(k_pnp_board, dim3((nframes + 63) / 64), dim3(64), 0, s, h->d_fc, nframes, h->d_board_obj,
-                     c.board_cols, c.board_rows, c.board_square, c.board_id, c.reference_mode, cam,
-                     h->d_img_scratch, h->d_det, h->d_ndet);
+  cam.solver = h->pnp_solver;
+  if (c.board_cols * c.board_rows > 8 && h->pnp_variant != 0)
+    hipLaunchKernelGGL(k_pnp_board_wave, dim3(nframes), dim3(64), 0, s, h->d_fc, nframes, h->d_board_obj,
+                       c.board_cols, c.board_rows, c.board_square, c.board_id, c.reference_mode, cam,
+                       h->d_img_scratch, h->d_det, h->d_ndet);
+  else
+    hipLaunchKernelGGL(k_pnp_board, dim3((nframes + 63) / 64), dim3(64), 0, s, h->d_fc, nframes, h->d_board_obj,
+                       c.board_cols, c.board_rows, c.board_square, c.board_id, c.reference_mode, cam,
+                       h->d_img_scratch, h->d_det, h->d_ndet);
   return hipGetLastError();
 }
 

@@ -126,6 +126,7 @@ hipError_t rcc_launch_synth(rcc_handle* h, const rcc_synth_params* sp, const dou
   a.cam.fx = c.K[0]; a.cam.cx = c.K[2]; a.cam.fy = c.K[4]; a.cam.cy = c.K[5];
   for (int i = 0; i < 8; ++i) a.cam.D[i] = c.D[i];
   a.cam.model = c.dist_model;
+  a.cam.solver = 0;
   a.ss = sp->supersample < 1 ? 1 : sp->supersample;
   a.nsx = sp->board_cols + 1; a.nsy = sp->board_rows + 1; a.margin = sp->margin_squares;
   a.sq = sp->board_square; a.sigma = sp->noise_sigma;

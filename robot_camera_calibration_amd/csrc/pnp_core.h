@@ -25,6 +25,15 @@
 #endif
 #endif
 
+// Device builds keep the big routines out of line: hipcc -O3 (ROCm 7.2) miscompiles the fully
+// inlined solver (wrong poses at 256 VGPRs + scratch; -O1 and the host build are right), and
+// separate frames also cut the spilling.  See DESIGN.md section 5.
+#if defined(__HIPCC__) && defined(RCC_PNP_NOINLINE)
+#define RCC_NI __attribute__((noinline))
+#else
+#define RCC_NI
+#endif
+
 #ifndef RCC_DIST_PLUMB_BOB
 #define RCC_DIST_NONE 0
 #define RCC_DIST_PLUMB_BOB 1
@@ -38,10 +47,11 @@ enum { PNP_OK = 0, PNP_TOO_FEW = 1, PNP_NONPLANAR = 2, PNP_DEGENERATE = 3 };
 struct Cam {
   double fx, fy, cx, cy;
   double k[5];  // k1,k2,p1,p2,k3 (zero when the model is NONE)
+  int solver;   // 0: eigen-decomposition solves (as published), 1: Cholesky with eigen fallback
 };
 
 // ---- symmetric eigen-decomposition (cyclic Jacobi), n <= 9; V rows = eigenvectors, w descending
-RCC_HD inline void jacobi_eigen_sym(int n, double* A, double* w, double* V)
+RCC_NI RCC_HD inline void jacobi_eigen_sym(int n, double* A, double* w, double* V)
 {
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
@@ -91,7 +101,7 @@ RCC_HD inline void jacobi_eigen_sym(int n, double* A, double* w, double* V)
 
 // x = pinv(A) b, symmetric A (n <= 8), singular directions dropped as cv::solve(DECOMP_SVD) does.
 // T, V: n*n scratch; w: n scratch.
-RCC_HD inline void sym_solve(int n, const double* A, const double* b, double* x, double* T, double* V, double* w)
+RCC_NI RCC_HD inline void sym_solve(int n, const double* A, const double* b, double* x, double* T, double* V, double* w)
 {
   for (int i = 0; i < n * n; ++i) T[i] = A[i];
   jacobi_eigen_sym(n, T, w, V);
@@ -108,6 +118,116 @@ RCC_HD inline void sym_solve(int n, const double* A, const double* b, double* x,
   }
 }
 
+// Cholesky solve for the symmetric positive definite normal equations (n <= 8).  The published
+// algorithm solves them by SVD (A.8) / eigen-decomposition (A.4); for a well-conditioned SPD matrix
+// the solutions agree to ~1e-12 relative.  A pivot below 1e-13 of the largest diagonal entry means
+// the SVD path would have dropped a direction: then fall back to sym_solve, which does.
+RCC_NI RCC_HD inline void spd_solve(int solver, int n, const double* A, const double* b, double* x, double* T, double* V, double* w)
+{
+  if (solver == 0) { sym_solve(n, A, b, x, T, V, w); return; }
+  double dmax = 0.0;
+  for (int i = 0; i < n; ++i) if (A[i * n + i] > dmax) dmax = A[i * n + i];
+  const double tiny = 1e-13 * dmax;
+  bool ok = dmax > 0.0;
+  // T = lower Cholesky factor
+  for (int j = 0; j < n && ok; ++j) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= T[j * n + k] * T[j * n + k];
+    if (!(d > tiny)) { ok = false; break; }
+    double dj = sqrt(d);
+    T[j * n + j] = dj;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= T[i * n + k] * T[j * n + k];
+      T[i * n + j] = s / dj;
+    }
+  }
+  if (!ok) { sym_solve(n, A, b, x, T, V, w); return; }
+  for (int i = 0; i < n; ++i) {            // L y = b
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= T[i * n + k] * x[k];
+    x[i] = s / T[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {       // L^T x = y
+    double s = x[i];
+    for (int k = i + 1; k < n; ++k) s -= T[k * n + i] * x[k];
+    x[i] = s / T[i * n + i];
+  }
+}
+
+// Eigenvector of the smallest eigenvalue of a symmetric positive semi-definite n x n matrix
+// (n <= 9): shifted inverse iteration on a Cholesky factor of M + delta*I.  The DLT matrix L^T L
+// has one eigenvalue that is (numerically) zero for consistent correspondences and a gap of many
+// orders of magnitude above it, so three iterations reach rounding level.  Returns 0 if the
+// factorization breaks down (caller then uses the Jacobi decomposition).  The published algorithm
+// takes this vector from a full eigen-decomposition (A.4); the vector is the same up to sign, and
+// the homography is normalised by H[2][2] afterwards.
+RCC_NI RCC_HD inline int smallest_eigvec_psd(int n, const double* M, double* x /* n */, double* L /* n*n scratch */)
+{
+  double tr = 0.0;
+  for (int i = 0; i < n; ++i) tr += M[i * n + i];
+  if (!(tr > 0.0)) return 0;
+  const double delta = 1e-14 * tr;
+  for (int j = 0; j < n; ++j) {
+    double d = M[j * n + j] + delta;
+    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+    if (!(d > 0.0)) return 0;
+    double dj = sqrt(d);
+    L[j * n + j] = dj;
+    for (int i = j + 1; i < n; ++i) {
+      double s = M[i * n + j];
+      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
+      L[i * n + j] = s / dj;
+    }
+  }
+  for (int i = 0; i < n; ++i) x[i] = 1.0 - 0.07 * i;
+  for (int it = 0; it < 4; ++it) {
+    for (int i = 0; i < n; ++i) {
+      double s = x[i];
+      for (int k = 0; k < i; ++k) s -= L[i * n + k] * x[k];
+      x[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = x[i];
+      for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
+      x[i] = s / L[i * n + i];
+    }
+    double nr = 0.0;
+    for (int i = 0; i < n; ++i) nr += x[i] * x[i];
+    if (!(nr > 0.0) || !isfinite(nr)) return 0;
+    nr = 1.0 / sqrt(nr);
+    for (int i = 0; i < n; ++i) x[i] *= nr;
+  }
+  return 1;
+}
+
+// How the per-point loops are spread: serially in one thread, or over the 64 lanes of a wavefront
+// (each lane takes points lane, lane+64, ...; sums are combined by an xor butterfly so that every
+// lane ends up with the same value and the scalar algebra that follows stays wave-uniform).
+struct SerialPar {
+  RCC_HD int first() const { return 0; }
+  RCC_HD int step() const { return 1; }
+  RCC_HD double sum(double v) const { return v; }
+  RCC_HD double max(double v) const { return v; }
+};
+#ifdef __HIPCC__
+struct WavePar {
+  int lane;
+  __device__ int first() const { return lane; }
+  __device__ int step() const { return 64; }
+  __device__ double sum(double v) const {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  }
+  __device__ double max(double v) const {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+  }
+};
+#endif
+
 RCC_HD inline void mat3_mul(const double* A, const double* B, double* C)
 {
   double T[9];
@@ -122,7 +242,7 @@ RCC_HD inline double mat3_det(const double* M)
 }
 
 // ---- a8 Rodrigues (appendix A.6) ---------------------------------------------------------------
-RCC_HD inline void rodrigues_v2m(const double r[3], double R[9], double* J /* 27 or null */)
+RCC_NI RCC_HD inline void rodrigues_v2m(const double r[3], double R[9], double* J /* 27 or null */)
 {
   double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
   if (theta < DBL_EPSILON) {
@@ -174,7 +294,7 @@ RCC_HD inline void orthonormalise3(const double* M, double* Q)
   mat3_mul(M, S, Q);
 }
 
-RCC_HD inline void rodrigues_m2v(const double Rin[9], double r[3])
+RCC_NI RCC_HD inline void rodrigues_m2v(const double Rin[9], double r[3])
 {
   double R[9];
   orthonormalise3(Rin, R);
@@ -282,12 +402,13 @@ RCC_HD inline void norm_point(const Pts& p, int i, const Cam& cm, bool has_dist,
 
 // residual sum S = |r|^2 of the homography h (8 params) and, when A != null, JtJ (8x8), Jtr (8),
 // max |r|
-RCC_HD inline double homography_accumulate(const double* h, const Pts& p, const double* Rt, const double* Tt,
+template <class Par>
+RCC_NI RCC_HD inline double homography_accumulate(const Par& par, const double* h, const Pts& p, const double* Rt, const double* Tt,
                                            const Cam& cm, bool has_dist, double* A, double* v, double* rinf)
 {
   if (A) { for (int i = 0; i < 64; ++i) A[i] = 0.0; for (int i = 0; i < 8; ++i) v[i] = 0.0; }
   double S = 0.0, ri = 0.0;
-  for (int i = 0; i < p.n; ++i) {
+  for (int i = par.first(); i < p.n; i += par.step()) {
     float Mxf, Myf, mxf, myf;
     plane_point(p, i, Rt, Tt, Mxf, Myf);
     norm_point(p, i, cm, has_dist, mxf, myf);
@@ -305,24 +426,32 @@ RCC_HD inline double homography_accumulate(const double* h, const Pts& p, const 
       double a[8] = { Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi };
       double b[8] = { 0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi };
       for (int r = 0; r < 8; ++r) {
-        for (int c = 0; c < 8; ++c) A[r * 8 + c] += a[r] * a[c] + b[r] * b[c];
+        for (int c = r; c < 8; ++c) A[r * 8 + c] += a[r] * a[c] + b[r] * b[c];
         v[r] += a[r] * e0 + b[r] * e1;
       }
     }
   }
-  if (rinf) *rinf = ri;
+  S = par.sum(S);
+  if (rinf) *rinf = par.max(ri);
+  if (A) {
+    for (int r = 0; r < 8; ++r) {
+      for (int c = r; c < 8; ++c) { A[r * 8 + c] = par.sum(A[r * 8 + c]); A[c * 8 + r] = A[r * 8 + c]; }
+      v[r] = par.sum(v[r]);
+    }
+  }
   return S;
 }
 
 // A.4, N > 4: the LMSolver refinement used by findHomography(method 0), <= 10 iterations
-RCC_HD inline void homography_refine(double* h, const Pts& p, const double* Rt, const double* Tt, const Cam& cm, bool has_dist)
+template <class Par>
+RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts& p, const double* Rt, const double* Tt, const Cam& cm, bool has_dist)
 {
   const int P = 8, maxIters = 10;
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
   double x[8], xd[8], A[64], Ap[64], v[8], d[8], Dg[8], tmp[8], T[64], V[64], w[8];
   for (int i = 0; i < 8; ++i) x[i] = h[i];
   double rinf = 0.0;
-  double S = homography_accumulate(x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
+  double S = homography_accumulate(par, x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
   for (int i = 0; i < P; ++i) Dg[i] = A[i * P + i];
   const double Rlo = 0.25, Rhi = 0.75;
   double lambda = 1.0, lc = 0.75;
@@ -330,9 +459,9 @@ RCC_HD inline void homography_refine(double* h, const Pts& p, const double* Rt, 
   for (;;) {
     for (int i = 0; i < 64; ++i) Ap[i] = A[i];
     for (int i = 0; i < P; ++i) Ap[i * P + i] += lambda * Dg[i];
-    sym_solve(P, Ap, v, d, T, V, w);
+    spd_solve(cm.solver, P, Ap, v, d, T, V, w);
     for (int i = 0; i < P; ++i) xd[i] = x[i] - d[i];
-    double Sd = homography_accumulate(xd, p, Rt, Tt, cm, has_dist, nullptr, nullptr, nullptr);
+    double Sd = homography_accumulate(par, xd, p, Rt, Tt, cm, has_dist, (double*)nullptr, (double*)nullptr, (double*)nullptr);
     double dS = 0.0;
     for (int a = 0; a < P; ++a) {
       double s = 0.0;
@@ -368,7 +497,7 @@ RCC_HD inline void homography_refine(double* h, const Pts& p, const double* Rt, 
     }
     if (Sd < S) {
       for (int i = 0; i < 8; ++i) x[i] = xd[i];
-      S = homography_accumulate(x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
+      S = homography_accumulate(par, x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
     }
     ++iter;
     double dinf = 0.0;
@@ -379,32 +508,35 @@ RCC_HD inline void homography_refine(double* h, const Pts& p, const double* Rt, 
 }
 
 // A.4: normalised DLT (+ refinement).  Returns 1 if H is finite.
-RCC_HD inline int find_homography(const Pts& p, const double* Rt, const double* Tt, const Cam& cm, bool has_dist, double H[9])
+template <class Par>
+RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const double* Rt, const double* Tt, const Cam& cm, bool has_dist, double H[9])
 {
   const int n = p.n;
   double cMx = 0, cMy = 0, cmx = 0, cmy = 0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = par.first(); i < n; i += par.step()) {
     float Mx, My, mx, my;
     plane_point(p, i, Rt, Tt, Mx, My);
     norm_point(p, i, cm, has_dist, mx, my);
     cMx += Mx; cMy += My; cmx += mx; cmy += my;
   }
+  cMx = par.sum(cMx); cMy = par.sum(cMy); cmx = par.sum(cmx); cmy = par.sum(cmy);
   cMx /= n; cMy /= n; cmx /= n; cmy /= n;
   double sMx = 0, sMy = 0, smx = 0, smy = 0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = par.first(); i < n; i += par.step()) {
     float Mx, My, mx, my;
     plane_point(p, i, Rt, Tt, Mx, My);
     norm_point(p, i, cm, has_dist, mx, my);
     sMx += fabs(Mx - cMx); sMy += fabs(My - cMy);
     smx += fabs(mx - cmx); smy += fabs(my - cmy);
   }
+  sMx = par.sum(sMx); sMy = par.sum(sMy); smx = par.sum(smx); smy = par.sum(smy);
   if (fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON || fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON) return 0;
   smx = n / smx; smy = n / smy; sMx = n / sMx; sMy = n / sMy;
   double invHnorm[9] = { 1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1 };
   double Hnorm2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
   double LtL[81], w[9], V[81];
   for (int i = 0; i < 81; ++i) LtL[i] = 0.0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = par.first(); i < n; i += par.step()) {
     float Mxf, Myf, mxf, myf;
     plane_point(p, i, Rt, Tt, Mxf, Myf);
     norm_point(p, i, cm, has_dist, mxf, myf);
@@ -415,28 +547,32 @@ RCC_HD inline int find_homography(const Pts& p, const double* Rt, const double* 
     for (int j = 0; j < 9; ++j)
       for (int k = j; k < 9; ++k) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
   }
-  for (int j = 0; j < 9; ++j) for (int k = 0; k < j; ++k) LtL[j * 9 + k] = LtL[k * 9 + j];
-  jacobi_eigen_sym(9, LtL, w, V);
+  for (int j = 0; j < 9; ++j)
+    for (int k = j; k < 9; ++k) { LtL[j * 9 + k] = par.sum(LtL[j * 9 + k]); LtL[k * 9 + j] = LtL[j * 9 + k]; }
   double H0[9], T[9];
-  for (int k = 0; k < 9; ++k) H0[k] = V[8 * 9 + k];
+  if (!(cm.solver == 1 && smallest_eigvec_psd(9, LtL, H0, V))) {
+    jacobi_eigen_sym(9, LtL, w, V);
+    for (int k = 0; k < 9; ++k) H0[k] = V[8 * 9 + k];
+  }
   mat3_mul(invHnorm, H0, T);
   mat3_mul(T, Hnorm2, H);
   double s = 1.0 / H[8];
   for (int k = 0; k < 9; ++k) H[k] *= s;
   H[8] = 1.0;
-  if (n > 4) homography_refine(H, p, Rt, Tt, cm, has_dist);
+  if (n > 4) homography_refine(par, H, p, Rt, Tt, cm, has_dist);
   for (int k = 0; k < 9; ++k) if (!isfinite(H[k])) return 0;
   return 1;
 }
 
 // normal equations of the pose LM at parameters prm (r,t): A = JtJ (6x6), g = Jte (6); returns |e|^2
-RCC_HD inline double pose_accumulate(const double* prm, const Pts& p, const Cam& cm, double* A, double* g)
+template <class Par>
+RCC_NI RCC_HD inline double pose_accumulate(const Par& par, const double* prm, const Pts& p, const Cam& cm, double* A, double* g)
 {
   double R[9], dRdr[27];
   rodrigues_v2m(prm, R, A ? dRdr : nullptr);
   if (A) { for (int i = 0; i < 36; ++i) A[i] = 0.0; for (int i = 0; i < 6; ++i) g[i] = 0.0; }
   double S = 0.0;
-  for (int i = 0; i < p.n; ++i) {
+  for (int i = par.first(); i < p.n; i += par.step()) {
     double uv[2], Ju[6], Jv[6];
     project_point(p.obj + 3 * i, R, dRdr, prm + 3, cm, uv, A ? Ju : nullptr, Jv);
     double e0 = uv[0] - p.img[2 * i], e1 = uv[1] - p.img[2 * i + 1];
@@ -444,29 +580,38 @@ RCC_HD inline double pose_accumulate(const double* prm, const Pts& p, const Cam&
     S += e1 * e1;
     if (A) {
       for (int a = 0; a < 6; ++a) {
-        for (int b = 0; b < 6; ++b) A[a * 6 + b] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+        for (int b = a; b < 6; ++b) A[a * 6 + b] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
         g[a] += Ju[a] * e0 + Jv[a] * e1;
       }
+    }
+  }
+  S = par.sum(S);
+  if (A) {
+    for (int a = 0; a < 6; ++a) {
+      for (int b = a; b < 6; ++b) { A[a * 6 + b] = par.sum(A[a * 6 + b]); A[b * 6 + a] = A[a * 6 + b]; }
+      g[a] = par.sum(g[a]);
     }
   }
   return S;
 }
 
 // A.1, A.3, A.5: the initial pose.  Returns a PNP_* status; prm = (r, t).
-RCC_HD inline int pose_init(const Pts& p, const Cam& cm, bool has_dist, double prm[6])
+template <class Par>
+RCC_NI RCC_HD inline int pose_init(const Par& par, const Pts& p, const Cam& cm, bool has_dist, double prm[6])
 {
   const int n = p.n;
   for (int i = 0; i < 6; ++i) prm[i] = 0.0;
   if (n < 4) return PNP_TOO_FEW;
   double Mc[3] = { 0, 0, 0 };
-  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) Mc[k] += p.obj[3 * i + k];
-  for (int k = 0; k < 3; ++k) Mc[k] /= n;
+  for (int i = par.first(); i < n; i += par.step()) for (int k = 0; k < 3; ++k) Mc[k] += p.obj[3 * i + k];
+  for (int k = 0; k < 3; ++k) Mc[k] = par.sum(Mc[k]) / n;
   double MM[9];
   for (int i = 0; i < 9; ++i) MM[i] = 0.0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = par.first(); i < n; i += par.step()) {
     double d[3] = { p.obj[3 * i] - Mc[0], p.obj[3 * i + 1] - Mc[1], p.obj[3 * i + 2] - Mc[2] };
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) MM[a * 3 + b] += d[a] * d[b];
   }
+  for (int i = 0; i < 9; ++i) MM[i] = par.sum(MM[i]);
   double W[3], Vt[9];
   jacobi_eigen_sym(3, MM, W, Vt);
   if (!(W[2] / W[1] < 1e-3)) return PNP_NONPLANAR;
@@ -480,7 +625,7 @@ RCC_HD inline int pose_init(const Pts& p, const Cam& cm, bool has_dist, double p
   for (int a = 0; a < 3; ++a) Tt[a] = -(Rt[a * 3] * Mc[0] + Rt[a * 3 + 1] * Mc[1] + Rt[a * 3 + 2] * Mc[2]);
   double H[9], R[9], t[3], r[3];
   int status = PNP_OK;
-  if (find_homography(p, Rt, Tt, cm, has_dist, H)) {
+  if (find_homography(par, p, Rt, Tt, cm, has_dist, H)) {
     double h1[3] = { H[0], H[3], H[6] }, h2[3] = { H[1], H[4], H[7] };
     t[0] = H[2]; t[1] = H[5]; t[2] = H[8];
     double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
@@ -508,7 +653,7 @@ RCC_HD inline int pose_init(const Pts& p, const Cam& cm, bool has_dist, double p
 // A, g when A != null -- it is the only place the points are touched, so a caller can supply a
 // wave-parallel (or MFMA) accumulation.
 template <class Accum>
-RCC_HD inline int pose_lm(double p[6], Accum accum, double* rms_sq_sum)
+RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* rms_sq_sum)
 {
   double pprev[6], A[36], g[6], Ap[36], dl[6], T[36], V[36], w[6];
   int L = -3, it = 0;
@@ -524,7 +669,7 @@ RCC_HD inline int pose_lm(double p[6], Accum accum, double* rms_sq_sum)
       double lambda = exp((double)L * log(10.0));
       for (int i = 0; i < 36; ++i) Ap[i] = A[i];
       for (int a = 0; a < 6; ++a) Ap[a * 6 + a] *= 1.0 + lambda;
-      sym_solve(6, Ap, g, dl, T, V, w);
+      spd_solve(solver, 6, Ap, g, dl, T, V, w);
       for (int a = 0; a < 6; ++a) p[a] = pprev[a] - dl[a];
       errNorm = sqrt(accum(p, (double*)nullptr, (double*)nullptr));
       if (errNorm > prevErr) {
@@ -543,14 +688,17 @@ RCC_HD inline int pose_lm(double p[6], Accum accum, double* rms_sq_sum)
   return it;
 }
 
-struct SerialAccum {
+template <class Par>
+struct ParAccum {
+  Par par;
   Pts p;
   Cam cm;
-  RCC_HD double operator()(const double* prm, double* A, double* g) const { return pose_accumulate(prm, p, cm, A, g); }
+  RCC_HD double operator()(const double* prm, double* A, double* g) const { return pose_accumulate(par, prm, p, cm, A, g); }
 };
 
-// whole solve, one thread
-RCC_HD inline int solve_pnp(const Pts& p, const Cam& cm_in, int dist_model, double rvec[3], double tvec[3], double* rms, int* iters)
+// whole solve; Par = SerialPar: one thread per target; Par = WavePar: one wavefront per target
+template <class Par>
+RCC_HD inline int solve_pnp(const Par& par, const Pts& p, const Cam& cm_in, int dist_model, double rvec[3], double tvec[3], double* rms, int* iters)
 {
   Cam cm = cm_in;
   const bool has_dist = (dist_model == RCC_DIST_PLUMB_BOB);
@@ -558,14 +706,14 @@ RCC_HD inline int solve_pnp(const Pts& p, const Cam& cm_in, int dist_model, doub
   double prm[6];
   if (rms) *rms = 0.0;
   if (iters) *iters = 0;
-  int status = pose_init(p, cm, has_dist, prm);
+  int status = pose_init(par, p, cm, has_dist, prm);
   if (status == PNP_TOO_FEW || status == PNP_NONPLANAR) {
     for (int k = 0; k < 3; ++k) { rvec[k] = 0.0; tvec[k] = 0.0; }
     return status;
   }
-  SerialAccum acc{ p, cm };
+  ParAccum<Par> acc{ par, p, cm };
   double ss = 0.0;
-  int it = pose_lm(prm, acc, &ss);
+  int it = pose_lm(prm, acc, cm.solver, &ss);
   for (int k = 0; k < 3; ++k) { rvec[k] = prm[k]; tvec[k] = prm[3 + k]; }
   if (rms) *rms = sqrt(ss / p.n);
   if (iters) *iters = it;

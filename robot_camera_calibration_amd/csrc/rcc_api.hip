@@ -138,6 +138,9 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->undist = cfg->undistort && cfg->dist_model != RCC_DIST_NONE;
   h->dense_variant = -1;
   h->ingest_variant = -1;
+  h->pnp_variant = -1;
+  h->pnp_solver = 1;
+  if (const char* e = getenv("RCC_PNP_SOLVER")) h->pnp_solver = atoi(e);
   h->sp.win = cfg->subpix_win;
   h->sp.max_iter = cfg->subpix_max_iter;
   h->sp.eps2 = cfg->subpix_eps * cfg->subpix_eps;
@@ -195,6 +198,13 @@ int rcc_set_dense_variant(rcc_handle* h, int variant)
   if (!h) return RCC_ERR_ARG;
   int p = h->dense_variant;
   h->dense_variant = variant;
+  return p;
+}
+int rcc_set_pnp_variant(rcc_handle* h, int variant)
+{
+  if (!h) return RCC_ERR_ARG;
+  int p = h->pnp_variant;
+  h->pnp_variant = variant;
   return p;
 }
 int rcc_set_ingest_variant(rcc_handle* h, int variant)
@@ -394,11 +404,14 @@ int rcc_solve_pnp_batch(rcc_handle* h, const double* obj, const double* img, con
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<int32_t> off((size_t)ntargets);
   size_t total = 0;
+  int maxpts = 0;
   for (int t = 0; t < ntargets; ++t) {
     if (npts[t] < 0) return RCC_ERR_ARG;
     off[t] = (int32_t)total;
     total += (size_t)npts[t];
+    if (npts[t] > maxpts) maxpts = npts[t];
   }
+  h->pnp_wave_hint = (maxpts > 8 && h->pnp_variant != 0) ? 1 : 0;
   const size_t T = (size_t)ntargets;
   // layout (8-byte units): obj[3*total] img[2*total] rvec[3T] tvec[3T] rms[T] | int32: off[T] npts[T] status[T] iters[T]
   const size_t nd = 5 * total + 7 * T;
@@ -425,12 +438,38 @@ int rcc_solve_pnp_batch(rcc_handle* h, const double* obj, const double* img, con
   cam.fx = Kp[0]; cam.cx = Kp[2]; cam.fy = Kp[4]; cam.cy = Kp[5];
   for (int i = 0; i < 8; ++i) cam.D[i] = (i < 5) ? Dp[i] : 0.0;
   cam.model = dist_model;
+  cam.solver = h->pnp_solver;
   HIPCHK(h, rcc_launch_pnp_generic(h, d_obj, d_img, d_off, d_npts, ntargets, cam, d_rvec, d_tvec, d_rms, d_status, d_iters, s));
   HIPCHK(h, hipMemcpyAsync(rvec, d_rvec, 3 * T * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(tvec, d_tvec, 3 * T * sizeof(double), hipMemcpyDeviceToHost, s));
   if (rms) HIPCHK(h, hipMemcpyAsync(rms, d_rms, T * sizeof(double), hipMemcpyDeviceToHost, s));
   if (status) HIPCHK(h, hipMemcpyAsync(status, d_status, T * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   if (iters) HIPCHK(h, hipMemcpyAsync(iters, d_iters, T * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return RCC_OK;
+}
+
+// test tap (host pointers): out[59] = H[9], initial pose[6], JtJ[36], Jte[6], |e|^2, status*10+ok
+int rcc_debug_pnp_probe(rcc_handle* h, const double* obj, const double* img, int32_t n, const double* K,
+                        const double* D, int32_t dist_model, double* out)
+{
+  if (!h || !obj || !img || n < 4 || !K || !D || !out) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  int r = ensure_pnp_buf(h, (size_t)(5 * n + 64) * sizeof(double));
+  if (r != RCC_OK) return r;
+  double* d_obj = h->d_pnp_buf;
+  double* d_img = d_obj + 3 * n;
+  double* d_out = d_img + 2 * n;
+  hipStream_t s = h->stream;
+  HIPCHK(h, hipMemcpyAsync(d_obj, obj, 3 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(d_img, img, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  rcc_cam cam;
+  cam.fx = K[0]; cam.cx = K[2]; cam.fy = K[4]; cam.cy = K[5];
+  for (int i = 0; i < 8; ++i) cam.D[i] = (i < 5) ? D[i] : 0.0;
+  cam.model = dist_model;
+  cam.solver = h->pnp_solver;
+  HIPCHK(h, rcc_launch_pnp_probe(d_obj, d_img, n, cam, d_out, s));
+  HIPCHK(h, hipMemcpyAsync(out, d_out, 59 * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
   return RCC_OK;
 }

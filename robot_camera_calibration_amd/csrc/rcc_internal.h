@@ -19,6 +19,7 @@ struct rcc_cam {
   double fx, fy, cx, cy;
   double D[8];
   int model;
+  int solver;   // PnP normal-equation solver: 0 eigen (as published), 1 Cholesky + eigen fallback
 };
 
 struct rcc_subpix_params {
@@ -57,6 +58,9 @@ struct rcc_handle {
   hipEvent_t ev[8];
   float last_ms[5];
   int dense_variant, ingest_variant;
+  int pnp_variant;          // -1 auto, 0 lane per target, 1 wavefront per target (board)
+  int pnp_solver;           // 0 eigen, 1 Cholesky (default)
+  int pnp_wave_hint;        // set per rcc_solve_pnp_batch call: max points per target > 8
   rcc_subpix_params sp;
   char err[256];
 };
@@ -74,6 +78,7 @@ hipError_t rcc_launch_pnp_generic(rcc_handle* h, const double* d_obj, const doub
                                   const int32_t* d_off, const int32_t* d_npts, int ntargets,
                                   rcc_cam cam, double* d_rvec, double* d_tvec, double* d_rms,
                                   int32_t* d_status, int32_t* d_iters, hipStream_t s);
+hipError_t rcc_launch_pnp_probe(const double* d_obj, const double* d_img, int n, rcc_cam cam, double* d_out, hipStream_t s);
 hipError_t rcc_launch_rodrigues(int dir, const double* d_in, int n, double* d_out, hipStream_t s);
 hipError_t rcc_launch_synth(rcc_handle* h, const rcc_synth_params* sp, const double* d_poses,
                             int nframes, int first_index, uint8_t* d_frames, hipStream_t s);

@@ -25,18 +25,18 @@ def shard_range(nframes, rank, world):
 def pack(dets, nslots, frame_offset=0):
     """rcc_detection records -> (nslots, REC) float64, zero-padded; slot = frame index in the batch."""
     a = np.zeros((nslots, REC), np.float64)
-    for d in dets:
-        r = a[d.frame]
-        r[0] = 1.0
-        r[1] = d.frame + frame_offset
-        r[2] = d.id
-        r[3] = d.ncorners
-        r[4:7] = d.rvec[:]
-        r[7:10] = d.tvec[:]
-        r[10] = d.rms
-        r[11] = d.corners[0][0]; r[12] = d.corners[0][1]
-        r[13] = d.corners[1][0]; r[14] = d.corners[1][1]
-        r[15] = d.corners[2][0]; r[16] = d.corners[2][1]
+    if len(dets) == 0:
+        return a
+    d = np.asarray(dets)
+    fr = d["frame"]
+    a[fr, 0] = 1.0
+    a[fr, 1] = fr + frame_offset
+    a[fr, 2] = d["id"]
+    a[fr, 3] = d["ncorners"]
+    a[fr, 4:7] = d["rvec"]
+    a[fr, 7:10] = d["tvec"]
+    a[fr, 10] = d["rms"]
+    a[fr, 11:17] = d["corners"].reshape(len(d), 8)[:, :6]
     return a
 
 

@@ -49,7 +49,7 @@ def _check_batch(torch, oracle, cfg, frames, n, expect_found=True):
     lst = det.fetch_lists(n)
     host = frames.cpu().numpy()
     ctx = oracle.Context(cfg)
-    by_frame = {d.frame: d for d in dets}
+    by_frame = {int(d.frame): d for d in dets}
     mx = dict(xy=0.0, pre_xy=0.0, rvec=0.0, tvec=0.0, rms=0.0)
     nc = cfg.board_cols * cfg.board_rows
     found = 0
@@ -242,3 +242,98 @@ def test_edge_cases(torch_cuda, oracle):
     bad.max_candidates = 0
     with pytest.raises(api.RccError):
         api.Detector(bad)
+
+
+@pytest.mark.parametrize("pixfmt", [abi.RCC_PIX_BGR8, abi.RCC_PIX_MONO8])
+def test_kernel_variants_bit_identical(torch_cuda, oracle, pixfmt):
+    """generic vs fast variants of the ingest and dense passes: same bytes, same candidate sets,
+    and both equal to the oracle"""
+    torch = torch_cuda
+    n = 5
+    cfg = _make(w=640, h=480, pixfmt=pixfmt, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch, det, cfg, n, seed=99)
+    px = cfg.width * cfg.height
+    outs = {}
+    for iv in (0, 1):
+        for dv in (0, 1):
+            det.set_ingest_variant(iv)
+            det.set_dense_variant(dv)
+            grey = torch.zeros((n, px), dtype=torch.uint8, device="cuda:0")
+            binm = torch.zeros((n, px), dtype=torch.uint8, device="cuda:0")
+            cand = torch.zeros((n, cfg.max_candidates * 8), dtype=torch.uint8, device="cuda:0")
+            cnt = torch.zeros((n,), dtype=torch.int32, device="cuda:0")
+            det.stage_ingest(frames, n, grey)
+            det.stage_threshold_corner(grey, n, binm, cand, cnt)
+            c = cand.cpu().numpy().view(api.CAND_DT).reshape(n, cfg.max_candidates)
+            k = cnt.cpu().numpy()
+            outs[(iv, dv)] = (grey.cpu().numpy(), binm.cpu().numpy(), [sorted_cands(c[f][:k[f]]) for f in range(n)], k)
+    ref = outs[(0, 0)]
+    for key, o in outs.items():
+        assert (o[0] == ref[0]).all(), "grey differs for variant %s" % (key,)
+        assert (o[1] == ref[1]).all(), "threshold map differs for variant %s" % (key,)
+        assert (o[3] == ref[3]).all()
+        for f in range(n):
+            assert (o[2][f] == ref[2][f]).all(), "candidates differ for variant %s frame %d" % (key, f)
+    host = frames.cpu().numpy()
+    ctx = oracle.Context(cfg)
+    for f in range(n):
+        k, odet, ofc, st = ctx.detect(host[f], f, stages=True)
+        assert (ref[0][f].reshape(cfg.height, cfg.width) == st["grey"]).all()
+        assert (ref[1][f].reshape(cfg.height, cfg.width) == st["bin"]).all()
+        assert (ref[2][f]["score"] == st["cand"]["score"]).all()
+    det.close()
+
+
+def test_full_size_properties(torch_cuda):
+    """1920x1080 (BASELINE.json's size), no oracle: size-independent properties of the path --
+    idempotence (same frames twice -> identical records), batch-order independence (a frame's
+    result does not depend on its batch slot), threshold map takes only {0,127,255}, candidate
+    lists sorted/unique after the list stage."""
+    torch = torch_cuda
+    n = 8
+    cfg = _make(w=1920, h=1080, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch, det, cfg, n, seed=1234)
+    d1, f1 = det.detect(frames, n)
+    img = det.fetch_images(n)
+    assert set(np.unique(img["bin"])) <= {0, 127, 255}
+    lst = det.fetch_lists(n)
+    for f in range(n):
+        p = lst["pre"][f][:lst["npre"][f]]
+        key = p["y"].astype(np.int64) * 65536 + p["x"]
+        assert (np.diff(key) > 0).all()
+    d2, f2 = det.detect(frames, n)
+    assert d1.tobytes() == d2.tobytes()
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device="cuda:0")
+    d3, f3 = det.detect(frames[perm].contiguous(), n)
+    by1 = {int(d.frame): d for d in d1}
+    for d in d3:
+        src = int(perm[d.frame])
+        assert list(d.rvec) == list(by1[src].rvec) and list(d.tvec) == list(by1[src].tvec)
+    assert len(d1) >= n - 1
+    det.close()
+
+
+def test_pnp_mappings_agree(torch_cuda, oracle):
+    """48-point board solves: lane-per-target and wavefront-per-target kernels vs the oracle"""
+    rng = np.random.default_rng(8)
+    cfg = _make(B=1)
+    det = api.Detector(cfg)
+    K = np.array(list(cfg.K)); D = np.array(list(cfg.D))
+    obj = synth.board_object_points(8, 6, 0.108)
+    poses = synth.sample_poses(40, cfg, seed=31)
+    imgs = [synth.project_points(obj, p[:3], p[3:], K, abi.RCC_DIST_PLUMB_BOB, D) + rng.normal(0, 0.05, (48, 2)) for p in poses]
+    res = {}
+    for v in (0, 1):
+        det.set_pnp_variant(v)
+        res[v] = det.solve_pnp([obj] * 40, imgs, K, D, abi.RCC_DIST_PLUMB_BOB)
+    worst = 0.0
+    for t in range(40):
+        st, r, tt, e, it = oracle.solve_pnp(obj, imgs[t], K, abi.RCC_DIST_PLUMB_BOB, D)
+        for v in (0, 1):
+            assert res[v][3][t] == st
+            worst = max(worst, np.abs(res[v][0][t] - r).max(), np.abs(res[v][1][t] - tt).max())
+    print("max |gpu - oracle| over 40 board solves, both mappings:", worst)
+    assert worst <= TOL
+    det.close()
