@@ -1,0 +1,95 @@
+// tag_detections_shim.cpp -- optional catkin target (NOT built in this repository's image: there is
+// no ROS here).  Drop-in for the external detector node the reference launches with
+//   roslaunch apriltag_ros continuous_detection.launch camera_name:=/cv_camera image_topic:=image_raw
+// (real_preprocessing/README.md:65): subscribes <camera_name>/<image_topic>, calls the C ABI
+// (include/rcc.h) and publishes "tag_detections" with exactly the fields the reference's consumer
+// reads -- detections[i].size[0], .id[0], .pixel_corners_x/y[0..3]
+// (real_preprocessing/src/corner_detections.cpp:46-54) -- so corner_detection_node,
+// camera_pose_node and opt_vis_node run unchanged.
+//
+// Intrinsics come from the same rosparams camera_pose_node reads:
+//   /camera_matrix/data (9 doubles, row-major), /distortion_coefficients/data (5 doubles)
+// (real_preprocessing/src/camera_pose.cpp:59-64).
+#include <ros/ros.h>
+#include <sensor_msgs/Image.h>
+#include <apriltag_ros/AprilTagDetectionArray.h>
+#include <vector>
+#include "rcc.h"
+
+class RccDetectorNode {
+ public:
+  explicit RccDetectorNode(ros::NodeHandle& nh) : nh_(nh), h_(nullptr), w_(0), h_px_(0) {
+    std::string cam, topic;
+    ros::NodeHandle pnh("~");
+    pnh.param<std::string>("camera_name", cam, "/cv_camera");
+    pnh.param<std::string>("image_topic", topic, "image_raw");
+    pub_ = nh_.advertise<apriltag_ros::AprilTagDetectionArray>("tag_detections", 1);
+    sub_ = nh_.subscribe(cam + "/" + topic, 1, &RccDetectorNode::onImage, this);   // queue 1, as the reference's consumer
+  }
+  ~RccDetectorNode() { rcc_destroy(h_); }
+
+ private:
+  bool ensureHandle(const sensor_msgs::Image& img) {
+    if (h_ && (int)img.width == w_ && (int)img.height == h_px_) return true;
+    rcc_destroy(h_);
+    h_ = nullptr;
+    rcc_config c;
+    rcc_default_config(&c);
+    c.width = img.width; c.height = img.height; c.stride_bytes = img.step;
+    c.pixfmt = (img.encoding == "mono8") ? RCC_PIX_MONO8 : RCC_PIX_BGR8;
+    c.frame_bytes = (int64_t)img.step * img.height;
+    std::vector<double> K, D;
+    if (!nh_.getParam("/camera_matrix/data", K) || !nh_.getParam("/distortion_coefficients/data", D) ||
+        K.size() != 9 || D.size() < 5) {
+      ROS_ERROR("Camera intrinsics not loaded to parameter server!");   // same message as camera_pose.cpp:67
+      return false;
+    }
+    for (int i = 0; i < 9; ++i) c.K[i] = K[i];
+    for (int i = 0; i < 5; ++i) c.D[i] = D[i];
+    c.dist_model = RCC_DIST_PLUMB_BOB;
+    c.batch_capacity = 1;
+    int st = rcc_create(&c, &h_);
+    if (st != RCC_OK) { ROS_ERROR("rcc_create: %s", rcc_status_string(st)); return false; }
+    w_ = img.width; h_px_ = img.height;
+    return true;
+  }
+
+  void onImage(const sensor_msgs::Image::ConstPtr& msg) {
+    if (!ensureHandle(*msg)) return;
+    rcc_detection det[4];
+    int32_t n = 0;
+    int st = rcc_detect_batch(h_, msg->data.data(), 1, RCC_MEM_HOST, det, &n, nullptr, nullptr);
+    if (st != RCC_OK) { ROS_ERROR_THROTTLE(1.0, "rcc_detect_batch: %s", rcc_status_string(st)); return; }
+    apriltag_ros::AprilTagDetectionArray out;
+    out.header = msg->header;
+    for (int i = 0; i < n; ++i) {
+      apriltag_ros::AprilTagDetection d;
+      d.id.push_back(det[i].id);                 // read as id[0]   (corner_detections.cpp:49)
+      d.size.push_back(det[i].size);             // read as size[0] (corner_detections.cpp:48)
+      for (int k = 0; k < 4; ++k) {              // bl, br, tr, tl  (camera_pose.cpp:123-126)
+        d.pixel_corners_x.push_back(det[i].corners[k][0]);
+        d.pixel_corners_y.push_back(det[i].corners[k][1]);
+      }
+      d.pose.header = msg->header;               // upstream field; the reference never reads it
+      d.pose.pose.pose.position.x = det[i].tvec[0];
+      d.pose.pose.pose.position.y = det[i].tvec[1];
+      d.pose.pose.pose.position.z = det[i].tvec[2];
+      out.detections.push_back(d);
+    }
+    pub_.publish(out);   // an empty array is skipped by the consumer (corner_detections.cpp:43)
+  }
+
+  ros::NodeHandle nh_;
+  ros::Publisher pub_;
+  ros::Subscriber sub_;
+  rcc_handle* h_;
+  int w_, h_px_;
+};
+
+int main(int argc, char** argv) {
+  ros::init(argc, argv, "rcc_detector");
+  ros::NodeHandle nh;
+  RccDetectorNode node(nh);
+  ros::spin();
+  return 0;
+}
