@@ -137,7 +137,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_dense.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_frame") * B   # PMC-derived, per frame x frames per launch
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "threshold+corner pass (k_dense_*)", "achieved": ach, "peak": HBM_PEAK_GBS,

@@ -227,6 +227,12 @@ int rcc_debug_fetch_lists(rcc_handle* h, int32_t nframes, void* pre, int32_t* np
 int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin, void* cand,
                            int32_t* cand_count);
 
+/* profiling aid: streaming copy with the dense pass's access width (4 B per lane), device pointers */
+int rcc_debug_calib_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes);
+/* test tap: intermediates of one PnP solve (host pointers), out[59] */
+int rcc_debug_pnp_probe(rcc_handle* h, const double* obj, const double* img, int32_t n, const double* K,
+                        const double* D, int32_t dist_model, double* out);
+
 /* ---- synthetic camera (stands where rviz_simulator's missing camera.h was meant to be,
  *      rviz_simulator/include/rviz_simulator/target.h:40) --------------------- */
 typedef struct rcc_synth_params {

@@ -74,6 +74,8 @@ def load_library():
     L.rcc_synth_render_batch.argtypes = [P, C.POINTER(abi.rcc_synth_params), P, I, I, P, P]
     L.rcc_debug_fetch_lists.argtypes = [P, I, P, P, P, P, P]
     L.rcc_debug_fetch_images.argtypes = [P, I, P, P, P, P]
+    L.rcc_debug_calib_copy.argtypes = [P, P, P, C.c_int64]
+    L.rcc_debug_calib_copy.restype = C.c_int
     for name in ("rcc_create", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
                  "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_stage_targets",
                  "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_last_timings", "rcc_time_dense",
@@ -91,7 +93,8 @@ EXPORTED_SYMBOLS = (
     "rcc_abi_version", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
     "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_set_dense_variant",
     "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
-    "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch",
+    "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch", "rcc_debug_calib_copy",
+    "rcc_debug_pnp_probe",
 )
 
 

@@ -381,6 +381,16 @@ int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin
   return RCC_OK;
 }
 
+// profiling aid: dword-per-lane streaming copy of nbytes (device pointers), see k_dense_fast.hip
+int rcc_debug_calib_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes)
+{
+  if (!h || !d_src || !d_dst || nbytes < 4) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, rcc_launch_calib_copy(d_src, d_dst, (size_t)nbytes, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RCC_OK;
+}
+
 // ---- solvePnP / Rodrigues drop-ins -----------------------------------------------------------------
 static int ensure_pnp_buf(rcc_handle* h, size_t bytes)
 {
