@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_ingest_gather(const uint8_t* __restrict
 // 16 BGR pixels per lane), converts each source pixel to grey ONCE, keeps the grey box in LDS
 // (double-buffered: the loads of frame f+1 are in flight while frame f's taps are taken), and reads
 // the four bilinear taps from LDS.  Out-of-image groups are zero (BORDER_CONSTANT 0).
-// Needs width % 16 == 0 and 16 B-aligned rows; a block whose box does not fit the LDS buffer
+// Needs width % 128 == 0, height % 8 == 0 and 16 B-aligned rows; a block whose box does not fit the LDS buffer
 // (strong magnification) takes the gather path for its tile.
 #define ST_TW 128
 #define ST_TH 8
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
                                                        rcc_cam cam, uint8_t* __restrict__ grey,
                                                        int nframes, int fpb)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t sbuf[2][ST_ROWS * ST_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t sbuf[2][ST_ROWS * ST_PITCH + 16];   // +16: dump slot of idle lanes
   __shared__ int s_red[4][4];
   const int tid = threadIdx.x;
   const int tx = tid & 31, ty = tid >> 5;           // 32 quads x 8 rows
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   const int gw = (spanx < 100000) ? (((mxx + 1) - bxa) / 16 + 1) : (1 << 20);
   const int bh = (spany < 100000) ? (mxy + 1 - mny + 1) : (1 << 20);
   const int by0 = mny;
-  const bool fits = (gw * 16 <= ST_PITCH) && (bh <= ST_ROWS);   // block-uniform
+  const bool fits = (gw * 16 <= ST_PITCH) && (bh <= ST_ROWS) && (gw <= 64) && (bh <= 4 * (64 / (gw > 0 ? gw : 1)));   // block-uniform
 
   if (!fits) {
     // gather path for this tile (same arithmetic, taps from global memory)
@@ -267,19 +267,15 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
     return;
   }
 
-  const int ngroups = gw * bh;                      // <= ST_MAXG = 384: at most 2 groups per thread
-  // group ids handled by this thread: tid and tid + 256
-  int gcol[2], grow[2];
-  bool gact[2], gin[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    int gidx = tid + 256 * q;
-    gact[q] = gidx < ngroups;
-    grow[q] = gact[q] ? gidx / gw : 0;
-    gcol[q] = gact[q] ? gidx - grow[q] * gw : 0;
-    int sx = bxa + 16 * gcol[q], sy = by0 + grow[q];
-    gin[q] = gact[q] && sx >= 0 && sx < w && sy >= 0 && sy < h;
-  }
+  // one 16-pixel group per thread: wave v takes box rows v, v+4, ...; consecutive lanes take
+  // consecutive groups of a row (coalesced 48 B per lane), so all four SIMDs share the load/convert work
+  const int wv = tid >> 6, ln = tid & 63;
+  const int grow = wv + 4 * (ln / gw), gcol = ln % gw;
+  const bool gact = grow < bh;
+  const int gsx = bxa + 16 * gcol, gsy = by0 + grow;
+  const bool gin = gact && gsx >= 0 && gsx < w && gsy >= 0 && gsy < h;
+  const size_t goff = gin ? ((size_t)gsy * stride + (size_t)gsx * NCH) : 0;
+  const int glds = grow * ST_PITCH + 16 * gcol;
   // tap offsets inside the LDS box (bytes)
   int toff[4], wts[4];
 #pragma unroll
@@ -288,50 +284,65 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
     wts[j] = ((X[j] & 31) << 8) | (Y[j] & 31);
   }
 
-  uint4 ra[2], rb[2], rd[2];
-  auto issue = [&](int f) {
-    const uint8_t* src = frames + (size_t)f * frame_bytes;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      ra[q] = make_uint4(0, 0, 0, 0); rb[q] = ra[q]; rd[q] = ra[q];
-      if (gin[q]) {
-        const uint8_t* p = src + (size_t)(by0 + grow[q]) * stride + (size_t)(bxa + 16 * gcol[q]) * NCH;
-        const uint4* p4 = reinterpret_cast<const uint4*>(p);
-        ra[q] = p4[0];
-        if (NCH == 3) { rb[q] = p4[1]; rd[q] = p4[2]; }
-      }
-    }
+  // Straight-line frame loop (the variant requires width % 128 == 0 and height % 8 == 0, so every
+  // thread owns 4 destination pixels): loads are unconditional -- an out-of-image group reads a
+  // clamped in-image address and is zeroed by a select (BORDER_CONSTANT 0), an idle lane re-reads
+  // group 0 -- so the compiler can count vmcnt instead of draining it.
+  struct Regs { uint4 a, b, d; };
+  const size_t goff_c = gin ? goff : ((size_t)min(max(gsy, 0), h - 1) * stride + (size_t)min(max(gsx, 0), w - 16) * NCH);
+  auto issue = [&](int f, Regs& r) {
+    const int fc = min(f, f1 - 1);
+    const uint4* p4 = reinterpret_cast<const uint4*>(frames + (size_t)fc * frame_bytes + goff_c);
+    r.a = p4[0];
+    if (NCH == 3) { r.b = p4[1]; r.d = p4[2]; }
   };
-  auto commit = [&](int b) {
+  const int glds_c = gact ? glds : (ST_ROWS * ST_PITCH);          // idle lanes write a dump slot past the box
+  auto commit = [&](uint8_t* buf, const Regs& r) {
+    uint4 gq = (NCH == 3) ? rcc_grey16(r.a, r.b, r.d) : r.a;
+    if (!gin) gq = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(buf + glds_c) = gq;
+  };
+  uint8_t* const out0 = grey + (size_t)y * w + x0;
+  auto taps = [&](int f, const uint8_t* L) {
+    uint32_t out = 0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (gact[q]) {
-        uint4 gq = (NCH == 3) ? (gin[q] ? rcc_grey16(ra[q], rb[q], rd[q]) : make_uint4(0, 0, 0, 0)) : ra[q];
-        *reinterpret_cast<uint4*>(&sbuf[b][grow[q] * ST_PITCH + 16 * gcol[q]]) = gq;
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int fx = wts[j] >> 8, fy = wts[j] & 31;
+      // aligned dword pairs + v_alignbyte: a misaligned ds_read_u16 serialises in the LDS
+      // (measured: ~48 LDS cycles per instruction, SQ_WAIT_INST_LDS = 51 % of wave time)
+      const uint32_t* t = reinterpret_cast<const uint32_t*>(L) + (toff[j] >> 2);
+      const uint32_t sh = (uint32_t)toff[j] & 3u;
+      const uint32_t top = __builtin_amdgcn_alignbyte(t[1], t[0], sh);
+      const uint32_t bot = __builtin_amdgcn_alignbyte(t[ST_PITCH / 4 + 1], t[ST_PITCH / 4], sh);
+      const int p00 = top & 255, p01 = (top >> 8) & 255, p10 = bot & 255, p11 = (bot >> 8) & 255;
+      int acc = (32 - fx) * (32 - fy) * p00 + fx * (32 - fy) * p01 + (32 - fx) * fy * p10 + fx * fy * p11;
+      out |= (uint32_t)((acc + 512) >> 10) << (8 * j);
     }
+    *reinterpret_cast<uint32_t*>(out0 + (size_t)f * w * h) = out;
   };
 
-  issue(f0);
-  commit(0);
-  for (int f = f0; f < f1; ++f) {
-    const int b = (f - f0) & 1;
-    __syncthreads();                                // buffer b complete; buffer b^1 free (its readers finished last iteration)
-    if (f + 1 < f1) issue(f + 1);
-    if (inside) {
-      const uint8_t* L = sbuf[b];
-      uint32_t out = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int fx = wts[j] >> 8, fy = wts[j] & 31;
-        const uint8_t* t = L + toff[j];
-        int p00 = t[0], p01 = t[1], p10 = t[ST_PITCH], p11 = t[ST_PITCH + 1];
-        int acc = (32 - fx) * (32 - fy) * p00 + fx * (32 - fy) * p01 + (32 - fx) * fy * p10 + fx * fy * p11;
-        out |= (uint32_t)((acc + 512) >> 10) << (8 * j);
-      }
-      *reinterpret_cast<uint32_t*>(grey + (size_t)f * w * h + (size_t)y * w + x0) = out;
-    }
-    if (f + 1 < f1) commit(b ^ 1);
+  // software pipeline, two frames of loads in flight: at step f the loads of f+2 are issued, the
+  // taps of f are taken from LDS buffer f&1, and frame f+1 (loaded two steps ago) is converted
+  // into buffer (f+1)&1.  Unrolled by two so the register sets keep static names.
+  uint8_t* const b0 = sbuf[0];
+  uint8_t* const b1 = sbuf[1];
+  Regs r0, r1;
+  issue(f0, r0);
+  issue(f0 + 1, r1);
+  commit(b0, r0);
+  for (int f = f0; f < f1; f += 2) {
+    __syncthreads();            // buffer 0 holds frame f; buffer 1 is free
+    issue(f + 2, r0);
+    __builtin_amdgcn_sched_barrier(0);    // keep the prefetch ahead of the taps and of the conversion
+    taps(f, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    commit(b1, r1);
+    __syncthreads();            // buffer 1 holds frame f+1 (if any); buffer 0 is free
+    issue(f + 3, r1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (f + 1 < f1) taps(f + 1, b1);      // block-uniform
+    __builtin_amdgcn_sched_barrier(0);
+    commit(b0, r0);
   }
 }
 
@@ -416,7 +427,7 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
   }
   rcc_cam cam = make_cam(c);
   int variant = h->ingest_variant;
-  const bool staged_ok = ((w & 15) == 0) && ((c.stride_bytes & 15) == 0) && ((c.frame_bytes & 15) == 0) &&
+  const bool staged_ok = ((w % ST_TW) == 0) && ((ht % ST_TH) == 0) && ((c.stride_bytes & 15) == 0) && ((c.frame_bytes & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0);
   if (variant < 0) variant = staged_ok ? 1 : 0;
   if (variant == 1 && staged_ok) {
