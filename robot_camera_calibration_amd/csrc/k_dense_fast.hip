@@ -23,12 +23,19 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int from_left(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, DPP_FROM_LEFT, 0xf, 0xf, false); }
 __device__ __forceinline__ int from_right(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, DPP_FROM_RIGHT, 0xf, 0xf, false); }
+// zero for lanes without a source (bound_ctrl:0): lets the compiler fold the move into the consumer
+__device__ __forceinline__ int from_left0(int v) { return __builtin_amdgcn_update_dpp(0, v, DPP_FROM_LEFT, 0xf, 0xf, true); }
+__device__ __forceinline__ int from_right0(int v) { return __builtin_amdgcn_update_dpp(0, v, DPP_FROM_RIGHT, 0xf, 0xf, true); }
 __device__ __forceinline__ i16x2 as_i(unsigned v) { return __builtin_bit_cast(i16x2, v); }
 __device__ __forceinline__ u16x2 as_u(unsigned v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ unsigned bits(i16x2 v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ unsigned bits(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
 struct HSum { int xx0, xy0, yy0, xx2, xy2, yy2; };   // raw 5-px row sums at pixel 0 and pixel 2 of the lane
+struct SobelRow { i16x2 dh01, dh23, sh01, sh23; };     // horizontal Sobel partials of one row (pixel pairs 0-1, 2-3)
+struct Tile4 { unsigned g0, g1, g2, g3; };             // grey dwords of the four rows of a tile row
+struct TStat { int hmin, hmax; };                      // horizontally dilated tile min / max
+struct LRow { int r0, r2, rL, rR; };                   // lattice row of responses: own px 0, px 2, left and right neighbour
 
 // ---- job geometry ----------------------------------------------------------------------------------
 #define STRIP_USE 244   // useful pixels per wave strip: lanes 2..62 (the left lattice neighbour of the
@@ -41,7 +48,8 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
                                                      int32_t* __restrict__ cand_count)
 {
   const int lane = threadIdx.x & 63;
-  const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // the job index is wave-uniform: tell the compiler, so strip/segment/frame/row arithmetic is scalar
+  const int job = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int njobs = nstrips * nseg * nframes;
   if (job >= njobs) return;
   const int strip = job % nstrips;
@@ -54,151 +62,162 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
   const int x0 = xs + 4 * lane;                         // first pixel of this lane
   const int xl = min(max(x0, 0), w - 4);                // clamped load column
   const bool lane_out = (lane >= 2) && (lane <= 62) && (x0 >= 0) && (x0 < w);
-  const uint8_t* g = grey + (size_t)f * w * h + xl;
-  uint8_t* bo = bin + (size_t)f * w * h + x0;
+  const uint8_t* gf = grey + (size_t)f * w * h;       // uniform; per-lane column offset xl is added at the load
+  uint8_t* bo = bin + (size_t)f * w * h;
   if (margin < 6) margin = 6;
 
-  // pipeline state
-  i16x2 dh01_a = 0, dh23_a = 0, sh01_a = 0, sh23_a = 0;   // row r-2
-  i16x2 dh01_b = 0, dh23_b = 0, sh01_b = 0, sh23_b = 0;   // row r-1
-  HSum hprev = { 0, 0, 0, 0, 0, 0 }, pa = { 0, 0, 0, 0, 0, 0 }, pb = { 0, 0, 0, 0, 0, 0 };
-  int rm0 = INT32_MIN, rm2 = INT32_MIN, rmL = INT32_MIN, rmR = INT32_MIN;   // lattice row y-4
-  int rc0 = INT32_MIN, rc2 = INT32_MIN, rcL = INT32_MIN, rcR = INT32_MIN;   // lattice row y-2
-  int hmin_a = 255, hmax_a = 0, hmin_b = 255, hmax_b = 0;                  // tile rows t-2, t-1 (horizontally dilated)
-  unsigned gp0 = 0, gp1 = 0, gp2 = 0, gp3 = 0;                              // grey of tile row t-1
+  // ---- pipeline state.  Roles rotate by RENAMING: the tile loop is unrolled by three and each
+  // unrolled copy gets the register sets in rotated order, so no state is moved between registers
+  // (Sobel partial sets rotate every row: 4 rows per tile row => offset 1 per tile row, period 3;
+  // grey tile buffers prev/cur/next and the tile statistics have period 3 as well).
+  SobelRow S0 = { 0, 0, 0, 0 }, S1 = S0, S2 = S0;
+  Tile4 T0 = { 0, 0, 0, 0 }, T1 = T0, T2 = T0;
+  TStat H0 = { 255, 0 }, H1 = H0, H2 = H0;
+  HSum hprev = { 0, 0, 0, 0, 0, 0 }, qa = hprev, qb = hprev;     // qa: pair closed at k=0, qb: pair closed at k=2
+  LRow Ra = { INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN }, Rb = Ra;   // lattice rows y-4, y-2
 
   auto load_row = [&](int r) -> unsigned {
-    int rr = min(max(r, 0), h - 1);
-    return *reinterpret_cast<const unsigned*>(g + (size_t)rr * w);
+    int rr = min(max(r, 0), h - 1);                     // scalar
+    return *reinterpret_cast<const unsigned*>(gf + (size_t)rr * w + xl);
+  };
+
+  // one image row: G = its grey dword; (a, b) = Sobel partials of rows r-2, r-1; n receives row r's.
+  auto do_row = [&](const int r, const int k, const unsigned G, const SobelRow& a, const SobelRow& b, SobelRow& n,
+                    u16x2& tmn, u16x2& tmx) {
+    // ---- stage A (row r): horizontal Sobel partials, natural-order pixel pairs
+    const unsigned GL = (unsigned)from_left((int)G, (int)G), GR = (unsigned)from_right((int)G, (int)G);
+    const u16x2 n0 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));    // [p0,p1]
+    const u16x2 n1 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C030C02u));    // [p2,p3]
+    const u16x2 mm = as_u(__builtin_amdgcn_perm(0u, G, 0x0C020C01u));    // [p1,p2]
+    const u16x2 lh = as_u(__builtin_amdgcn_perm(GL, G, 0x0C000C07u));    // [p-1,p0]
+    const u16x2 rh = as_u(__builtin_amdgcn_perm(GR, G, 0x0C040C03u));    // [p3,p4]
+    tmn = __builtin_elementwise_min(tmn, __builtin_elementwise_min(n0, n1));
+    tmx = __builtin_elementwise_max(tmx, __builtin_elementwise_max(n0, n1));
+    const i16x2 two = (i16x2)(2);
+    n.dh01 = as_i(bits(mm)) - as_i(bits(lh));                            // I[x+1]-I[x-1] for x = p0,p1
+    n.dh23 = as_i(bits(rh)) - as_i(bits(mm));
+    n.sh01 = as_i(bits(n0)) * two + as_i(bits(lh)) + as_i(bits(mm));     // I[x-1]+2I[x]+I[x+1]
+    n.sh23 = as_i(bits(n1)) * two + as_i(bits(mm)) + as_i(bits(rh));
+    // ---- stage B (row rho = r-1): gradients
+    const i16x2 gx01 = (b.dh01 * two + a.dh01 + n.dh01) >> 3;
+    const i16x2 gx23 = (b.dh23 * two + a.dh23 + n.dh23) >> 3;
+    const i16x2 gy01 = (n.sh01 - a.sh01) >> 3;
+    const i16x2 gy23 = (n.sh23 - a.sh23) >> 3;
+    // ---- stage C (row rho): products + horizontal 5-sums at pixels 0 and 2
+    const int d0xx = __builtin_amdgcn_sdot2(gx01, gx01, 0, false);
+    const int d0xy = __builtin_amdgcn_sdot2(gx01, gy01, 0, false);
+    const int d0yy = __builtin_amdgcn_sdot2(gy01, gy01, 0, false);
+    const int d1xx = __builtin_amdgcn_sdot2(gx23, gx23, 0, false);
+    const int d1xy = __builtin_amdgcn_sdot2(gx23, gy23, 0, false);
+    const int d1yy = __builtin_amdgcn_sdot2(gy23, gy23, 0, false);
+    const int ax0 = gx01.x, ay0 = gy01.x, ax2 = gx23.x, ay2 = gy23.x;
+    const int q0xx = __mul24(ax0, ax0), q0xy = __mul24(ax0, ay0), q0yy = __mul24(ay0, ay0);
+    const int q2xx = __mul24(ax2, ax2), q2xy = __mul24(ax2, ay2), q2yy = __mul24(ay2, ay2);
+    HSum hc;
+    hc.xx0 = d0xx + q2xx + from_left0(d1xx);
+    hc.xy0 = d0xy + q2xy + from_left0(d1xy);
+    hc.yy0 = d0yy + q2yy + from_left0(d1yy);
+    hc.xx2 = d0xx + d1xx + from_right0(q0xx);
+    hc.xy2 = d0xy + d1xy + from_right0(q0xy);
+    hc.yy2 = d0yy + d1yy + from_right0(q0yy);
+    // ---- stage D/E/F: vertical sums on the lattice, response, selection
+    if ((k & 1) == 0) {
+      // rho = r-1 is odd: close the pair (rho-1, rho) into qa (k = 0) or qb (k = 2)
+      HSum& q = (k == 0) ? qa : qb;
+      q.xx0 = hprev.xx0 + hc.xx0; q.xy0 = hprev.xy0 + hc.xy0; q.yy0 = hprev.yy0 + hc.yy0;
+      q.xx2 = hprev.xx2 + hc.xx2; q.xy2 = hprev.xy2 + hc.xy2; q.yy2 = hprev.yy2 + hc.yy2;
+    } else {
+      // rho = r-1 is even: 5-row sums centred on y = rho-2 = the two closed pairs + this row
+      const int A0 = (qa.xx0 + qb.xx0 + hc.xx0) >> 4, B0 = (qa.xy0 + qb.xy0 + hc.xy0) >> 4, C0 = (qa.yy0 + qb.yy0 + hc.yy0) >> 4;
+      const int A2 = (qa.xx2 + qb.xx2 + hc.xx2) >> 4, B2 = (qa.xy2 + qb.xy2 + hc.xy2) >> 4, C2 = (qa.yy2 + qb.yy2 + hc.yy2) >> 4;
+      const unsigned tr0 = (unsigned)(A0 + C0), tr2 = (unsigned)(A2 + C2);
+      LRow Rn;
+      Rn.r0 = __mul24(A0, C0) - __mul24(B0, B0) - (int)(__umul24(tr0, tr0) >> 4);
+      Rn.r2 = __mul24(A2, C2) - __mul24(B2, B2) - (int)(__umul24(tr2, tr2) >> 4);
+      Rn.rL = from_left(Rn.r2, INT32_MIN);
+      Rn.rR = from_right(Rn.r0, INT32_MIN);
+      hprev = hc;
+      // selection on lattice row yc = rho - 4 = r - 5 (rows Ra = yc-2, Rb = yc, Rn = yc+2)
+      const int yc = r - 5;
+      const bool rowok = (yc >= 4 * t0) && (yc < 4 * t1) && (yc >= margin) && (yc < h - margin);
+      if (rowok && __any((Rb.r0 >= hthresh) || (Rb.r2 >= hthresh))) {
+        const int xa = x0, xb = x0 + 2;
+        bool is0 = lane_out && Rb.r0 >= hthresh && xa >= margin && xa < w - margin &&
+                   Rb.r0 > Ra.rL && Rb.r0 > Ra.r0 && Rb.r0 > Ra.r2 && Rb.r0 > Rb.rL &&
+                   Rb.r0 >= Rb.r2 && Rb.r0 >= Rn.rL && Rb.r0 >= Rn.r0 && Rb.r0 >= Rn.r2;
+        bool is2 = lane_out && Rb.r2 >= hthresh && xb >= margin && xb < w - margin &&
+                   Rb.r2 > Ra.r0 && Rb.r2 > Ra.r2 && Rb.r2 > Ra.rR && Rb.r2 > Rb.r0 &&
+                   Rb.r2 >= Rb.rR && Rb.r2 >= Rn.r0 && Rb.r2 >= Rn.r2 && Rb.r2 >= Rn.rR;
+        const unsigned long long m0 = __ballot(is0), m2 = __ballot(is2);
+        const int n0c = __popcll(m0), n2c = __popcll(m2);
+        if (n0c + n2c) {
+          int basei = 0;
+          if (lane == 0) basei = atomicAdd(&cand_count[f], n0c + n2c);
+          basei = __shfl(basei, 0);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (is0) {
+            int idx = basei + __popcll(m0 & below);
+            if (idx < cap) { rcc_cand e; e.x = (int16_t)xa; e.y = (int16_t)yc; e.score = Rb.r0; cand[(size_t)f * cap + idx] = e; }
+          }
+          if (is2) {
+            int idx = basei + n0c + __popcll(m2 & below);
+            if (idx < cap) { rcc_cand e; e.x = (int16_t)xb; e.y = (int16_t)yc; e.score = Rb.r2; cand[(size_t)f * cap + idx] = e; }
+          }
+        }
+      }
+      Ra = Rb;
+      Rb = Rn;
+    }
+  };
+
+  // one tile row t: P / C / N = grey of tile rows t-1 / t / t+1 (N is loaded here), ha / hb = tile
+  // statistics of rows t-2 / t-1, hn receives row t's; (sa, sb, sc) = Sobel sets in role order
+  auto do_tile = [&](const int t, const Tile4& P, const Tile4& C, Tile4& N, const TStat& ha, const TStat& hb, TStat& hn,
+                     SobelRow& sa, SobelRow& sb, SobelRow& sc) {
+    N.g0 = load_row(4 * t + 4); N.g1 = load_row(4 * t + 5); N.g2 = load_row(4 * t + 6); N.g3 = load_row(4 * t + 7);
+    u16x2 tmn = (u16x2)(255), tmx = (u16x2)(0);
+    do_row(4 * t + 0, 0, C.g0, sa, sb, sc, tmn, tmx);
+    do_row(4 * t + 1, 1, C.g1, sb, sc, sa, tmn, tmx);
+    do_row(4 * t + 2, 2, C.g2, sc, sa, sb, tmn, tmx);
+    do_row(4 * t + 3, 3, C.g3, sa, sb, sc, tmn, tmx);
+    // ---- stage G: threshold.  Statistics of tile row t, then output of tile row t-1.
+    const int tmin = min((int)tmn.x, (int)tmn.y), tmax = max((int)tmx.x, (int)tmx.y);
+    hn.hmin = min(tmin, min(from_left(tmin, tmin), from_right(tmin, tmin)));
+    hn.hmax = max(tmax, max(from_left(tmax, tmax), from_right(tmax, tmax)));
+    const int dmin = min(ha.hmin, min(hb.hmin, hn.hmin)), dmax = max(ha.hmax, max(hb.hmax, hn.hmax));
+    const int range = dmax - dmin;
+    const int thr = dmin + (range >> 1);
+    const bool flat = range < min_contrast;
+    const int tt = t - 1;
+    if (tt >= t0 && tt < t1 && lane_out) {
+      // per byte: v > thr  <=>  v >= thr+1 (thr <= 254 whenever the tile is not flat).  SWAR unsigned
+      // byte compare: d = (x|H) - (y&~H) has its per-byte MSB set iff the low 7 bits of x >= those of y
+      // (no borrow crosses bytes); where the MSBs of x and y differ x's decides, else d's.
+      const unsigned H = 0x80808080u;
+      const unsigned y4 = (unsigned)(thr + 1) * 0x01010101u;
+      const unsigned ylo = y4 & ~H, ny = ~y4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned x = (k == 0) ? P.g0 : (k == 1) ? P.g1 : (k == 2) ? P.g2 : P.g3;
+        const unsigned d = (x | H) - ylo;
+        const unsigned xy = x ^ y4;
+        const unsigned ge = (((x & ny) & xy) | (d & ~xy)) & H;      // bitfield select on xy
+        unsigned o = (ge >> 7) * 255u;                               // 0x01 -> 0xFF per byte, no carries
+        if (flat) o = 0x7F7F7F7Fu;
+        *reinterpret_cast<unsigned*>(bo + (size_t)(4 * tt + k) * w + x0) = o;
+      }
+    }
   };
 
   int t = t0 - 2;
-  unsigned gc0 = load_row(4 * t), gc1 = load_row(4 * t + 1), gc2 = load_row(4 * t + 2), gc3 = load_row(4 * t + 3);
-
-  for (; t <= t1; ++t) {
-    // prefetch the next tile row
-    unsigned gn0 = load_row(4 * t + 4), gn1 = load_row(4 * t + 5), gn2 = load_row(4 * t + 6), gn3 = load_row(4 * t + 7);
-    u16x2 tmn = (u16x2)(255), tmx = (u16x2)(0);
-
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned G = (k == 0) ? gc0 : (k == 1) ? gc1 : (k == 2) ? gc2 : gc3;
-      const int r = 4 * t + k;
-      // ---- stage A (row r): horizontal Sobel partials, natural-order pixel pairs
-      const unsigned GL = (unsigned)from_left((int)G, (int)G), GR = (unsigned)from_right((int)G, (int)G);
-      const u16x2 n0 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));    // [p0,p1]
-      const u16x2 n1 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C030C02u));    // [p2,p3]
-      const u16x2 mm = as_u(__builtin_amdgcn_perm(0u, G, 0x0C020C01u));    // [p1,p2]
-      const u16x2 lh = as_u(__builtin_amdgcn_perm(GL, G, 0x0C000C07u));    // [p-1,p0]
-      const u16x2 rh = as_u(__builtin_amdgcn_perm(GR, G, 0x0C040C03u));    // [p3,p4]
-      tmn = __builtin_elementwise_min(tmn, __builtin_elementwise_min(n0, n1));
-      tmx = __builtin_elementwise_max(tmx, __builtin_elementwise_max(n0, n1));
-      const i16x2 dh01 = as_i(bits(mm)) - as_i(bits(lh));                 // I[x+1]-I[x-1] for x = p0,p1
-      const i16x2 dh23 = as_i(bits(rh)) - as_i(bits(mm));
-      const i16x2 sh01 = as_i(bits(lh)) + as_i(bits(n0)) + as_i(bits(n0)) + as_i(bits(mm));   // I[x-1]+2I[x]+I[x+1]
-      const i16x2 sh23 = as_i(bits(mm)) + as_i(bits(n1)) + as_i(bits(n1)) + as_i(bits(rh));
-      // ---- stage B (row rho = r-1): gradients
-      const i16x2 gx01 = (dh01_a + dh01_b + dh01_b + dh01) >> 3;
-      const i16x2 gx23 = (dh23_a + dh23_b + dh23_b + dh23) >> 3;
-      const i16x2 gy01 = (sh01 - sh01_a) >> 3;
-      const i16x2 gy23 = (sh23 - sh23_a) >> 3;
-      dh01_a = dh01_b; dh23_a = dh23_b; sh01_a = sh01_b; sh23_a = sh23_b;
-      dh01_b = dh01; dh23_b = dh23; sh01_b = sh01; sh23_b = sh23;
-      // ---- stage C (row rho): products + horizontal 5-sums at pixels 0 and 2
-      const int d0xx = __builtin_amdgcn_sdot2(gx01, gx01, 0, false);
-      const int d0xy = __builtin_amdgcn_sdot2(gx01, gy01, 0, false);
-      const int d0yy = __builtin_amdgcn_sdot2(gy01, gy01, 0, false);
-      const int d1xx = __builtin_amdgcn_sdot2(gx23, gx23, 0, false);
-      const int d1xy = __builtin_amdgcn_sdot2(gx23, gy23, 0, false);
-      const int d1yy = __builtin_amdgcn_sdot2(gy23, gy23, 0, false);
-      const int ax0 = gx01.x, ay0 = gy01.x, ax2 = gx23.x, ay2 = gy23.x;
-      const int q0xx = __mul24(ax0, ax0), q0xy = __mul24(ax0, ay0), q0yy = __mul24(ay0, ay0);
-      const int q2xx = __mul24(ax2, ax2), q2xy = __mul24(ax2, ay2), q2yy = __mul24(ay2, ay2);
-      HSum hc;
-      hc.xx0 = d0xx + q2xx + from_left(d1xx, 0);
-      hc.xy0 = d0xy + q2xy + from_left(d1xy, 0);
-      hc.yy0 = d0yy + q2yy + from_left(d1yy, 0);
-      hc.xx2 = d0xx + d1xx + from_right(q0xx, 0);
-      hc.xy2 = d0xy + d1xy + from_right(q0xy, 0);
-      hc.yy2 = d0yy + d1yy + from_right(q0yy, 0);
-      // ---- stage D/E/F: vertical sums on the lattice, response, selection
-      if ((k & 1) == 0) {
-        // rho = r-1 is odd: close the pair (rho-1, rho)
-        pa = pb;
-        pb.xx0 = hprev.xx0 + hc.xx0; pb.xy0 = hprev.xy0 + hc.xy0; pb.yy0 = hprev.yy0 + hc.yy0;
-        pb.xx2 = hprev.xx2 + hc.xx2; pb.xy2 = hprev.xy2 + hc.xy2; pb.yy2 = hprev.yy2 + hc.yy2;
-      } else {
-        // rho = r-1 is even: 5-row sums centred on y = rho-2, response there
-        const int A0 = (pa.xx0 + pb.xx0 + hc.xx0) >> 4, B0 = (pa.xy0 + pb.xy0 + hc.xy0) >> 4, C0 = (pa.yy0 + pb.yy0 + hc.yy0) >> 4;
-        const int A2 = (pa.xx2 + pb.xx2 + hc.xx2) >> 4, B2 = (pa.xy2 + pb.xy2 + hc.xy2) >> 4, C2 = (pa.yy2 + pb.yy2 + hc.yy2) >> 4;
-        const unsigned tr0 = (unsigned)(A0 + C0), tr2 = (unsigned)(A2 + C2);
-        const int rn0 = __mul24(A0, C0) - __mul24(B0, B0) - (int)(__umul24(tr0, tr0) >> 4);
-        const int rn2 = __mul24(A2, C2) - __mul24(B2, B2) - (int)(__umul24(tr2, tr2) >> 4);
-        const int rnL = from_left(rn2, INT32_MIN), rnR = from_right(rn0, INT32_MIN);
-        hprev = hc;
-        // selection on lattice row yc = rho - 4 = r - 5 (rows rm = yc-2, rc = yc, rn = yc+2)
-        const int yc = r - 5;
-        const bool rowok = (yc >= 4 * t0) && (yc < 4 * t1) && (yc >= margin) && (yc < h - margin);
-        if (rowok && __any((rc0 >= hthresh) || (rc2 >= hthresh))) {
-          const int xa = x0, xb = x0 + 2;
-          bool is0 = lane_out && rc0 >= hthresh && xa >= margin && xa < w - margin &&
-                     rc0 > rmL && rc0 > rm0 && rc0 > rm2 && rc0 > rcL &&
-                     rc0 >= rc2 && rc0 >= rnL && rc0 >= rn0 && rc0 >= rn2;
-          bool is2 = lane_out && rc2 >= hthresh && xb >= margin && xb < w - margin &&
-                     rc2 > rm0 && rc2 > rm2 && rc2 > rmR && rc2 > rc0 &&
-                     rc2 >= rcR && rc2 >= rn0 && rc2 >= rn2 && rc2 >= rnR;
-          const unsigned long long m0 = __ballot(is0), m2 = __ballot(is2);
-          const int n0c = __popcll(m0), n2c = __popcll(m2);
-          if (n0c + n2c) {
-            int basei = 0;
-            if (lane == 0) basei = atomicAdd(&cand_count[f], n0c + n2c);
-            basei = __shfl(basei, 0);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (is0) {
-              int idx = basei + __popcll(m0 & below);
-              if (idx < cap) { rcc_cand e; e.x = (int16_t)xa; e.y = (int16_t)yc; e.score = rc0; cand[(size_t)f * cap + idx] = e; }
-            }
-            if (is2) {
-              int idx = basei + n0c + __popcll(m2 & below);
-              if (idx < cap) { rcc_cand e; e.x = (int16_t)xb; e.y = (int16_t)yc; e.score = rc2; cand[(size_t)f * cap + idx] = e; }
-            }
-          }
-        }
-        rm0 = rc0; rm2 = rc2; rmL = rcL; rmR = rcR;
-        rc0 = rn0; rc2 = rn2; rcL = rnL; rcR = rnR;
-      }
-    }
-
-    // ---- stage G: threshold.  Statistics of tile row t, then output of tile row t-1.
-    int tmin = min((int)tmn.x, (int)tmn.y), tmax = max((int)tmx.x, (int)tmx.y);
-    int hmin = min(tmin, min(from_left(tmin, tmin), from_right(tmin, tmin)));
-    int hmax = max(tmax, max(from_left(tmax, tmax), from_right(tmax, tmax)));
-    {
-      const int dmin = min(hmin_a, min(hmin_b, hmin)), dmax = max(hmax_a, max(hmax_b, hmax));
-      const int range = dmax - dmin;
-      const int thr = dmin + (range >> 1);
-      const bool flat = range < min_contrast;
-      const int tt = t - 1;
-      if (tt >= t0 && tt < t1 && lane_out) {
-        const u16x2 thr2 = (u16x2)((unsigned short)thr);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned G = (k == 0) ? gp0 : (k == 1) ? gp1 : (k == 2) ? gp2 : gp3;
-          const u16x2 a = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));
-          const u16x2 b = as_u(__builtin_amdgcn_perm(0u, G, 0x0C030C02u));
-          // v > thr ? 255 : 0 per 16-bit half: saturating (v - thr), clamp to 1, times 255
-          u16x2 da = __builtin_elementwise_sub_sat(a, thr2), db = __builtin_elementwise_sub_sat(b, thr2);
-          da = __builtin_elementwise_min(da, (u16x2)(1)) * (u16x2)(255);
-          db = __builtin_elementwise_min(db, (u16x2)(1)) * (u16x2)(255);
-          unsigned o = __builtin_amdgcn_perm(bits(db), bits(da), 0x06040200u);   // bytes [a.lo, a.hi, b.lo, b.hi]
-          if (flat) o = 0x7F7F7F7Fu;
-          *reinterpret_cast<unsigned*>(bo + (size_t)(4 * tt + k) * w) = o;
-        }
-      }
-    }
-    hmin_a = hmin_b; hmax_a = hmax_b; hmin_b = hmin; hmax_b = hmax;
-    gp0 = gc0; gp1 = gc1; gp2 = gc2; gp3 = gc3;
-    gc0 = gn0; gc1 = gn1; gc2 = gn2; gc3 = gn3;
+  T1.g0 = load_row(4 * t); T1.g1 = load_row(4 * t + 1); T1.g2 = load_row(4 * t + 2); T1.g3 = load_row(4 * t + 3);
+  for (;;) {
+    do_tile(t, T0, T1, T2, H0, H1, H2, S0, S1, S2);
+    if (++t > t1) break;
+    do_tile(t, T1, T2, T0, H1, H2, H0, S1, S2, S0);
+    if (++t > t1) break;
+    do_tile(t, T2, T0, T1, H2, H0, H1, S2, S0, S1);
+    if (++t > t1) break;
   }
 }
 
