@@ -99,6 +99,58 @@ RCC_NI RCC_HD inline void jacobi_eigen_sym(int n, double* A, double* w, double* 
   }
 }
 
+// 3x3 version with static indices (registers on the device); same sweep rule, same ordering
+RCC_HD inline void jacobi_eigen_sym3(double* A, double* w, double* V)
+{
+#pragma unroll
+  for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    const double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
+    const double diag = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
+    if (off <= 1e-300 || off <= 1e-34 * diag) break;
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
+      const double apq = A[p * 3 + q];
+      if (apq == 0.0) continue;
+      const double app = A[p * 3 + p], aqq = A[q * 3 + q];
+      const double theta = (aqq - app) / (2.0 * apq);
+      double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+      if (theta < 0.0) t = -t;
+      const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double akp = A[k * 3 + p], akq = A[k * 3 + q];
+        A[k * 3 + p] = c * akp - sn * akq;
+        A[k * 3 + q] = sn * akp + c * akq;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double apk = A[p * 3 + k], aqk = A[q * 3 + k];
+        A[p * 3 + k] = c * apk - sn * aqk;
+        A[q * 3 + k] = sn * apk + c * aqk;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double vpk = V[p * 3 + k], vqk = V[q * 3 + k];
+        V[p * 3 + k] = c * vpk - sn * vqk;
+        V[q * 3 + k] = sn * vpk + c * vqk;
+      }
+    }
+  }
+  w[0] = A[0]; w[1] = A[4]; w[2] = A[8];
+  // sort descending with static compare-exchanges (0,1) (0,2) (1,2); rows of V follow
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int i = (s3 == 2) ? 1 : 0, j = (s3 == 0) ? 1 : 2;
+    if (w[j] > w[i]) {
+      double t = w[i]; w[i] = w[j]; w[j] = t;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { double u = V[i * 3 + k]; V[i * 3 + k] = V[j * 3 + k]; V[j * 3 + k] = u; }
+    }
+  }
+}
+
 // x = pinv(A) b, symmetric A (n <= 8), singular directions dropped as cv::solve(DECOMP_SVD) does.
 // T, V: n*n scratch; w: n scratch.
 RCC_NI RCC_HD inline void sym_solve(int n, const double* A, const double* b, double* x, double* T, double* V, double* w)
@@ -118,40 +170,64 @@ RCC_NI RCC_HD inline void sym_solve(int n, const double* A, const double* b, dou
   }
 }
 
-// Cholesky solve for the symmetric positive definite normal equations (n <= 8).  The published
+// Cholesky solve for the symmetric positive definite normal equations (N = 6 or 8, compile time:
+// fully unrolled, the factor lives in registers).  The published
 // algorithm solves them by SVD (A.8) / eigen-decomposition (A.4); for a well-conditioned SPD matrix
 // the solutions agree to ~1e-12 relative.  A pivot below 1e-13 of the largest diagonal entry means
 // the SVD path would have dropped a direction: then fall back to sym_solve, which does.
-RCC_NI RCC_HD inline void spd_solve(int solver, int n, const double* A, const double* b, double* x, double* T, double* V, double* w)
+template <int N>
+RCC_HD inline void spd_solve(int solver, const double* A, const double* b, double* x)
 {
-  if (solver == 0) { sym_solve(n, A, b, x, T, V, w); return; }
-  double dmax = 0.0;
-  for (int i = 0; i < n; ++i) if (A[i * n + i] > dmax) dmax = A[i * n + i];
-  const double tiny = 1e-13 * dmax;
-  bool ok = dmax > 0.0;
-  // T = lower Cholesky factor
-  for (int j = 0; j < n && ok; ++j) {
-    double d = A[j * n + j];
-    for (int k = 0; k < j; ++k) d -= T[j * n + k] * T[j * n + k];
-    if (!(d > tiny)) { ok = false; break; }
-    double dj = sqrt(d);
-    T[j * n + j] = dj;
-    for (int i = j + 1; i < n; ++i) {
-      double s = A[i * n + j];
-      for (int k = 0; k < j; ++k) s -= T[i * n + k] * T[j * n + k];
-      T[i * n + j] = s / dj;
+  bool ok = (solver != 0);
+  double L[N * N];
+  if (ok) {
+    double dmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) if (A[i * N + i] > dmax) dmax = A[i * N + i];
+    const double tiny = 1e-13 * dmax;
+    ok = dmax > 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      double d = A[j * N + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
+      if (!(d > tiny)) ok = false;
+      const double dj = sqrt(d > tiny ? d : 1.0);
+      L[j * N + j] = dj;
+      const double idj = 1.0 / dj;
+#pragma unroll
+      for (int i = j + 1; i < N; ++i) {
+        double t = A[i * N + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) t -= L[i * N + k] * L[j * N + k];
+        L[i * N + j] = t * idj;
+      }
     }
   }
-  if (!ok) { sym_solve(n, A, b, x, T, V, w); return; }
-  for (int i = 0; i < n; ++i) {            // L y = b
-    double s = b[i];
-    for (int k = 0; k < i; ++k) s -= T[i * n + k] * x[k];
-    x[i] = s / T[i * n + i];
+  if (!ok) {
+    // eigen-decomposition path (as published; also the ill-conditioned fallback): private copies,
+    // so that the arrays above never have their address taken
+    double A2[N * N], b2[N], x2[N], T[N * N], V[N * N], w[N];
+    for (int i = 0; i < N * N; ++i) A2[i] = A[i];
+    for (int i = 0; i < N; ++i) b2[i] = b[i];
+    sym_solve(N, A2, b2, x2, T, V, w);
+    for (int i = 0; i < N; ++i) x[i] = x2[i];
+    return;
   }
-  for (int i = n - 1; i >= 0; --i) {       // L^T x = y
-    double s = x[i];
-    for (int k = i + 1; k < n; ++k) s -= T[k * n + i] * x[k];
-    x[i] = s / T[i * n + i];
+  double y[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {            // L y = b
+    double t = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) t -= L[i * N + k] * y[k];
+    y[i] = t / L[i * N + i];
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {       // L^T x = y
+    double t = y[i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) t -= L[k * N + i] * x[k];
+    x[i] = t / L[i * N + i];
   }
 }
 
@@ -162,41 +238,59 @@ RCC_NI RCC_HD inline void spd_solve(int solver, int n, const double* A, const do
 // factorization breaks down (caller then uses the Jacobi decomposition).  The published algorithm
 // takes this vector from a full eigen-decomposition (A.4); the vector is the same up to sign, and
 // the homography is normalised by H[2][2] afterwards.
-RCC_NI RCC_HD inline int smallest_eigvec_psd(int n, const double* M, double* x /* n */, double* L /* n*n scratch */)
+template <int N>
+RCC_HD inline int smallest_eigvec_psd(const double* M, double* x /* N */)
 {
+  double L[N * N];
   double tr = 0.0;
-  for (int i = 0; i < n; ++i) tr += M[i * n + i];
+#pragma unroll
+  for (int i = 0; i < N; ++i) tr += M[i * N + i];
   if (!(tr > 0.0)) return 0;
   const double delta = 1e-14 * tr;
-  for (int j = 0; j < n; ++j) {
-    double d = M[j * n + j] + delta;
-    for (int k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
-    if (!(d > 0.0)) return 0;
-    double dj = sqrt(d);
-    L[j * n + j] = dj;
-    for (int i = j + 1; i < n; ++i) {
-      double s = M[i * n + j];
-      for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
-      L[i * n + j] = s / dj;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double d = M[j * N + j] + delta;
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
+    if (!(d > 0.0)) ok = false;
+    const double dj = sqrt(d > 0.0 ? d : 1.0);
+    L[j * N + j] = dj;
+    const double idj = 1.0 / dj;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double t = M[i * N + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * N + k] * L[j * N + k];
+      L[i * N + j] = t * idj;
     }
   }
-  for (int i = 0; i < n; ++i) x[i] = 1.0 - 0.07 * i;
+  if (!ok) return 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = 1.0 - 0.07 * i;
+#pragma unroll 1
   for (int it = 0; it < 4; ++it) {
-    for (int i = 0; i < n; ++i) {
-      double s = x[i];
-      for (int k = 0; k < i; ++k) s -= L[i * n + k] * x[k];
-      x[i] = s / L[i * n + i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double t = x[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) t -= L[i * N + k] * x[k];
+      x[i] = t / L[i * N + i];
     }
-    for (int i = n - 1; i >= 0; --i) {
-      double s = x[i];
-      for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
-      x[i] = s / L[i * n + i];
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+      double t = x[i];
+#pragma unroll
+      for (int k = i + 1; k < N; ++k) t -= L[k * N + i] * x[k];
+      x[i] = t / L[i * N + i];
     }
     double nr = 0.0;
-    for (int i = 0; i < n; ++i) nr += x[i] * x[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) nr += x[i] * x[i];
     if (!(nr > 0.0) || !isfinite(nr)) return 0;
     nr = 1.0 / sqrt(nr);
-    for (int i = 0; i < n; ++i) x[i] *= nr;
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] *= nr;
   }
   return 1;
 }
@@ -231,8 +325,11 @@ struct WavePar {
 RCC_HD inline void mat3_mul(const double* A, const double* B, double* C)
 {
   double T[9];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+#pragma unroll
   for (int i = 0; i < 9; ++i) C[i] = T[i];
 }
 
@@ -242,12 +339,14 @@ RCC_HD inline double mat3_det(const double* M)
 }
 
 // ---- a8 Rodrigues (appendix A.6) ---------------------------------------------------------------
-RCC_NI RCC_HD inline void rodrigues_v2m(const double r[3], double R[9], double* J /* 27 or null */)
+RCC_HD inline void rodrigues_v2m(const double r[3], double R[9], double* J /* 27 or null */)
 {
   double theta = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
   if (theta < DBL_EPSILON) {
+#pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
     if (J) {
+#pragma unroll
       for (int i = 0; i < 27; ++i) J[i] = 0.0;
       J[5] = J[15] = J[19] = -1.0;
       J[7] = J[11] = J[21] = 1.0;
@@ -258,6 +357,7 @@ RCC_NI RCC_HD inline void rodrigues_v2m(const double r[3], double R[9], double* 
   double rx = r[0] * it, ry = r[1] * it, rz = r[2] * it;
   double rrt[9] = { rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz };
   double rxm[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };
+#pragma unroll
   for (int k = 0; k < 9; ++k) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * rxm[k];
   if (J) {
     double drrt[27] = { rx + rx, ry, rz, ry, 0, 0, rz, 0, 0,
@@ -266,9 +366,11 @@ RCC_NI RCC_HD inline void rodrigues_v2m(const double r[3], double R[9], double* 
     const double drxm[27] = { 0, 0, 0, 0, 0, -1, 0, 1, 0,
                               0, 0, 1, 0, 0, 0, -1, 0, 0,
                               0, -1, 0, 1, 0, 0, 0, 0, 0 };
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
       double ri = (i == 0) ? rx : (i == 1) ? ry : rz;
       double a0 = -s * ri, a1 = (s - 2.0 * c1 * it) * ri, a2 = c1 * it, a3 = (c - s * it) * ri, a4 = s * it;
+#pragma unroll
       for (int k = 0; k < 9; ++k)
         J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * rxm[k] + a4 * drxm[i * 9 + k];
     }
@@ -278,13 +380,18 @@ RCC_NI RCC_HD inline void rodrigues_v2m(const double r[3], double R[9], double* 
 RCC_HD inline void orthonormalise3(const double* M, double* Q)
 {
   double MtM[9], w[3], V[9];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) MtM[i * 3 + j] = M[i] * M[j] + M[3 + i] * M[3 + j] + M[6 + i] * M[6 + j];
-  jacobi_eigen_sym(3, MtM, w, V);
+  jacobi_eigen_sym3(MtM, w, V);
   double S[9];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       double a = 0.0;
+#pragma unroll
       for (int k = 0; k < 3; ++k) {
         double iw = (w[k] > 1e-300) ? 1.0 / sqrt(w[k]) : 0.0;
         a += V[k * 3 + i] * iw * V[k * 3 + j];
@@ -294,7 +401,7 @@ RCC_HD inline void orthonormalise3(const double* M, double* Q)
   mat3_mul(M, S, Q);
 }
 
-RCC_NI RCC_HD inline void rodrigues_m2v(const double Rin[9], double r[3])
+RCC_HD inline void rodrigues_m2v(const double Rin[9], double r[3])
 {
   double R[9];
   orthonormalise3(Rin, R);
@@ -357,6 +464,7 @@ RCC_HD inline void project_point(const double M[3], const double R[9], const dou
   uv[0] = xd * cm.fx + cm.cx;
   uv[1] = yd * cm.fy + cm.cy;
   if (!Ju) return;
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
     double dxj, dyj;
     if (j < 3) {
@@ -403,7 +511,7 @@ RCC_HD inline void norm_point(const Pts& p, int i, const Cam& cm, bool has_dist,
 // residual sum S = |r|^2 of the homography h (8 params) and, when A != null, JtJ (8x8), Jtr (8),
 // max |r|
 template <class Par>
-RCC_NI RCC_HD inline double homography_accumulate(const Par& par, const double* h, const Pts& p, const double* Rt, const double* Tt,
+RCC_HD inline double homography_accumulate(const Par& par, const double* h, const Pts& p, const double* Rt, const double* Tt,
                                            const Cam& cm, bool has_dist, double* A, double* v, double* rinf)
 {
   if (A) { for (int i = 0; i < 64; ++i) A[i] = 0.0; for (int i = 0; i < 8; ++i) v[i] = 0.0; }
@@ -425,7 +533,9 @@ RCC_NI RCC_HD inline double homography_accumulate(const Par& par, const double* 
     if (A) {
       double a[8] = { Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi };
       double b[8] = { 0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi };
+#pragma unroll
       for (int r = 0; r < 8; ++r) {
+#pragma unroll
         for (int c = r; c < 8; ++c) A[r * 8 + c] += a[r] * a[c] + b[r] * b[c];
         v[r] += a[r] * e0 + b[r] * e1;
       }
@@ -434,7 +544,9 @@ RCC_NI RCC_HD inline double homography_accumulate(const Par& par, const double* 
   S = par.sum(S);
   if (rinf) *rinf = par.max(ri);
   if (A) {
+#pragma unroll
     for (int r = 0; r < 8; ++r) {
+#pragma unroll
       for (int c = r; c < 8; ++c) { A[r * 8 + c] = par.sum(A[r * 8 + c]); A[c * 8 + r] = A[r * 8 + c]; }
       v[r] = par.sum(v[r]);
     }
@@ -448,23 +560,30 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
 {
   const int P = 8, maxIters = 10;
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
-  double x[8], xd[8], A[64], Ap[64], v[8], d[8], Dg[8], tmp[8], T[64], V[64], w[8];
+  double x[8], xd[8], A[64], Ap[64], v[8], d[8], Dg[8], tmp[8];
+#pragma unroll
   for (int i = 0; i < 8; ++i) x[i] = h[i];
   double rinf = 0.0;
   double S = homography_accumulate(par, x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
+#pragma unroll
   for (int i = 0; i < P; ++i) Dg[i] = A[i * P + i];
   const double Rlo = 0.25, Rhi = 0.75;
   double lambda = 1.0, lc = 0.75;
   int iter = 0;
   for (;;) {
+#pragma unroll
     for (int i = 0; i < 64; ++i) Ap[i] = A[i];
+#pragma unroll
     for (int i = 0; i < P; ++i) Ap[i * P + i] += lambda * Dg[i];
-    spd_solve(cm.solver, P, Ap, v, d, T, V, w);
+    spd_solve<8>(cm.solver, Ap, v, d);
+#pragma unroll
     for (int i = 0; i < P; ++i) xd[i] = x[i] - d[i];
     double Sd = homography_accumulate(par, xd, p, Rt, Tt, cm, has_dist, (double*)nullptr, (double*)nullptr, (double*)nullptr);
     double dS = 0.0;
+#pragma unroll
     for (int a = 0; a < P; ++a) {
       double s = 0.0;
+#pragma unroll
       for (int b = 0; b < P; ++b) s += A[a * P + b] * d[b];
       tmp[a] = -s + 2.0 * v[a];
       dS += d[a] * tmp[a];
@@ -475,18 +594,24 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
       if (lambda < lc) lambda = 0.0;
     } else if (Rr < Rlo) {
       double t = 0.0;
+#pragma unroll
       for (int a = 0; a < P; ++a) t += d[a] * v[a];
       double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1.0) + 2.0;
       nu = nu < 2.0 ? 2.0 : (nu > 10.0 ? 10.0 : nu);
       if (lambda == 0.0) {
+        double T[64], V[64], w[8];
+#pragma unroll
         for (int i = 0; i < 64; ++i) T[i] = A[i];
         jacobi_eigen_sym(P, T, w, V);
         double thr = 0.0;
+#pragma unroll
         for (int i = 0; i < P; ++i) thr += fabs(w[i]);
         thr *= 2.0 * DBL_EPSILON;
         double maxval = DBL_EPSILON;
+#pragma unroll
         for (int a = 0; a < P; ++a) {
           double s = 0.0;
+#pragma unroll
           for (int i = 0; i < P; ++i) if (fabs(w[i]) > thr) s += V[i * P + a] * V[i * P + a] / w[i];
           if (fabs(s) > maxval) maxval = fabs(s);
         }
@@ -496,14 +621,17 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
       lambda *= nu;
     }
     if (Sd < S) {
+#pragma unroll
       for (int i = 0; i < 8; ++i) x[i] = xd[i];
       S = homography_accumulate(par, x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
     }
     ++iter;
     double dinf = 0.0;
+#pragma unroll
     for (int i = 0; i < P; ++i) if (fabs(d[i]) > dinf) dinf = fabs(d[i]);
     if (!(iter < maxIters && dinf >= epsx && rinf >= epsf)) break;
   }
+#pragma unroll
   for (int i = 0; i < 8; ++i) h[i] = x[i];
 }
 
@@ -534,7 +662,8 @@ RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const dou
   smx = n / smx; smy = n / smy; sMx = n / sMx; sMy = n / sMy;
   double invHnorm[9] = { 1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1 };
   double Hnorm2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
-  double LtL[81], w[9], V[81];
+  double LtL[81];
+#pragma unroll
   for (int i = 0; i < 81; ++i) LtL[i] = 0.0;
   for (int i = par.first(); i < n; i += par.step()) {
     float Mxf, Myf, mxf, myf;
@@ -544,29 +673,39 @@ RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const dou
     double X = (Mxf - cMx) * sMx, Y = (Myf - cMy) * sMy;
     double Lx[9] = { X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x };
     double Ly[9] = { 0, 0, 0, X, Y, 1, -y * X, -y * Y, -y };
+#pragma unroll
     for (int j = 0; j < 9; ++j)
+#pragma unroll
       for (int k = j; k < 9; ++k) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
   }
+#pragma unroll
   for (int j = 0; j < 9; ++j)
+#pragma unroll
     for (int k = j; k < 9; ++k) { LtL[j * 9 + k] = par.sum(LtL[j * 9 + k]); LtL[k * 9 + j] = LtL[j * 9 + k]; }
   double H0[9], T[9];
-  if (!(cm.solver == 1 && smallest_eigvec_psd(9, LtL, H0, V))) {
-    jacobi_eigen_sym(9, LtL, w, V);
+  if (!(cm.solver == 1 && smallest_eigvec_psd<9>(LtL, H0))) {
+    double L2[81], w[9], V[81];                       // full decomposition (as published / fallback): private copies
+#pragma unroll
+    for (int k = 0; k < 81; ++k) L2[k] = LtL[k];
+    jacobi_eigen_sym(9, L2, w, V);
+#pragma unroll
     for (int k = 0; k < 9; ++k) H0[k] = V[8 * 9 + k];
   }
   mat3_mul(invHnorm, H0, T);
   mat3_mul(T, Hnorm2, H);
   double s = 1.0 / H[8];
+#pragma unroll
   for (int k = 0; k < 9; ++k) H[k] *= s;
   H[8] = 1.0;
   if (n > 4) homography_refine(par, H, p, Rt, Tt, cm, has_dist);
+#pragma unroll
   for (int k = 0; k < 9; ++k) if (!isfinite(H[k])) return 0;
   return 1;
 }
 
 // normal equations of the pose LM at parameters prm (r,t): A = JtJ (6x6), g = Jte (6); returns |e|^2
 template <class Par>
-RCC_NI RCC_HD inline double pose_accumulate(const Par& par, const double* prm, const Pts& p, const Cam& cm, double* A, double* g)
+RCC_HD inline double pose_accumulate(const Par& par, const double* prm, const Pts& p, const Cam& cm, double* A, double* g)
 {
   double R[9], dRdr[27];
   rodrigues_v2m(prm, R, A ? dRdr : nullptr);
@@ -579,7 +718,9 @@ RCC_NI RCC_HD inline double pose_accumulate(const Par& par, const double* prm, c
     S += e0 * e0;
     S += e1 * e1;
     if (A) {
+#pragma unroll
       for (int a = 0; a < 6; ++a) {
+#pragma unroll
         for (int b = a; b < 6; ++b) A[a * 6 + b] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
         g[a] += Ju[a] * e0 + Jv[a] * e1;
       }
@@ -587,7 +728,9 @@ RCC_NI RCC_HD inline double pose_accumulate(const Par& par, const double* prm, c
   }
   S = par.sum(S);
   if (A) {
+#pragma unroll
     for (int a = 0; a < 6; ++a) {
+#pragma unroll
       for (int b = a; b < 6; ++b) { A[a * 6 + b] = par.sum(A[a * 6 + b]); A[b * 6 + a] = A[a * 6 + b]; }
       g[a] = par.sum(g[a]);
     }
@@ -600,28 +743,36 @@ template <class Par>
 RCC_NI RCC_HD inline int pose_init(const Par& par, const Pts& p, const Cam& cm, bool has_dist, double prm[6])
 {
   const int n = p.n;
+#pragma unroll
   for (int i = 0; i < 6; ++i) prm[i] = 0.0;
   if (n < 4) return PNP_TOO_FEW;
   double Mc[3] = { 0, 0, 0 };
   for (int i = par.first(); i < n; i += par.step()) for (int k = 0; k < 3; ++k) Mc[k] += p.obj[3 * i + k];
+#pragma unroll
   for (int k = 0; k < 3; ++k) Mc[k] = par.sum(Mc[k]) / n;
   double MM[9];
+#pragma unroll
   for (int i = 0; i < 9; ++i) MM[i] = 0.0;
   for (int i = par.first(); i < n; i += par.step()) {
     double d[3] = { p.obj[3 * i] - Mc[0], p.obj[3 * i + 1] - Mc[1], p.obj[3 * i + 2] - Mc[2] };
+#pragma unroll
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) MM[a * 3 + b] += d[a] * d[b];
   }
+#pragma unroll
   for (int i = 0; i < 9; ++i) MM[i] = par.sum(MM[i]);
   double W[3], Vt[9];
-  jacobi_eigen_sym(3, MM, W, Vt);
+  jacobi_eigen_sym3(MM, W, Vt);
   if (!(W[2] / W[1] < 1e-3)) return PNP_NONPLANAR;
   double Rt[9];
+#pragma unroll
   for (int k = 0; k < 9; ++k) Rt[k] = Vt[k];
   if (Vt[2] * Vt[2] + Vt[5] * Vt[5] < 1e-10) {
+#pragma unroll
     for (int k = 0; k < 9; ++k) Rt[k] = (k % 4 == 0) ? 1.0 : 0.0;
   }
   if (mat3_det(Rt) < 0) for (int k = 0; k < 9; ++k) Rt[k] = -Rt[k];
   double Tt[3];
+#pragma unroll
   for (int a = 0; a < 3; ++a) Tt[a] = -(Rt[a * 3] * Mc[0] + Rt[a * 3 + 1] * Mc[1] + Rt[a * 3 + 2] * Mc[2]);
   double H[9], R[9], t[3], r[3];
   int status = PNP_OK;
@@ -630,21 +781,26 @@ RCC_NI RCC_HD inline int pose_init(const Par& par, const Pts& p, const Cam& cm, 
     t[0] = H[2]; t[1] = H[5]; t[2] = H[8];
     double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
     double n2 = sqrt(h2[0] * h2[0] + h2[1] * h2[1] + h2[2] * h2[2]);
+#pragma unroll
     for (int k = 0; k < 3; ++k) { h1[k] /= n1; h2[k] /= n2; t[k] *= 2.0 / (n1 + n2); }
     double h3[3] = { h1[1] * h2[2] - h1[2] * h2[1], h1[2] * h2[0] - h1[0] * h2[2], h1[0] * h2[1] - h1[1] * h2[0] };
     double R0[9] = { h1[0], h2[0], h3[0], h1[1], h2[1], h3[1], h1[2], h2[2], h3[2] };
     rodrigues_m2v(R0, r);
     rodrigues_v2m(r, R, nullptr);
     double t2[3];
+#pragma unroll
     for (int a = 0; a < 3; ++a) t2[a] = R[a * 3] * Tt[0] + R[a * 3 + 1] * Tt[1] + R[a * 3 + 2] * Tt[2] + t[a];
+#pragma unroll
     for (int a = 0; a < 3; ++a) t[a] = t2[a];
     mat3_mul(R, Rt, R);
   } else {
     status = PNP_DEGENERATE;
+#pragma unroll
     for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
     t[0] = t[1] = t[2] = 0.0;
   }
   rodrigues_m2v(R, r);
+#pragma unroll
   for (int k = 0; k < 3; ++k) { prm[k] = r[k]; prm[3 + k] = t[k]; }
   return status;
 }
@@ -655,21 +811,25 @@ RCC_NI RCC_HD inline int pose_init(const Par& par, const Pts& p, const Cam& cm, 
 template <class Accum>
 RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* rms_sq_sum)
 {
-  double pprev[6], A[36], g[6], Ap[36], dl[6], T[36], V[36], w[6];
+  double pprev[6], A[36], g[6], Ap[36], dl[6];
   int L = -3, it = 0;
   double prevErr = 0.0;
   const int max_iter = 20;
   const double eps = FLT_EPSILON;
   for (;;) {
     double S0 = accum(p, A, g);
+#pragma unroll
     for (int a = 0; a < 6; ++a) pprev[a] = p[a];
     if (it == 0) prevErr = sqrt(S0);
     double errNorm;
     for (;;) {
       double lambda = exp((double)L * log(10.0));
+#pragma unroll
       for (int i = 0; i < 36; ++i) Ap[i] = A[i];
+#pragma unroll
       for (int a = 0; a < 6; ++a) Ap[a * 6 + a] *= 1.0 + lambda;
-      spd_solve(solver, 6, Ap, g, dl, T, V, w);
+      spd_solve<6>(solver, Ap, g, dl);
+#pragma unroll
       for (int a = 0; a < 6; ++a) p[a] = pprev[a] - dl[a];
       errNorm = sqrt(accum(p, (double*)nullptr, (double*)nullptr));
       if (errNorm > prevErr) {
@@ -679,6 +839,7 @@ RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* r
     }
     L = (L - 1 > -16) ? L - 1 : -16;
     double dn = 0.0, pn = 0.0;
+#pragma unroll
     for (int a = 0; a < 6; ++a) { dn += (p[a] - pprev[a]) * (p[a] - pprev[a]); pn += pprev[a] * pprev[a]; }
     double rel = sqrt(dn) / sqrt(pn);
     if (++it >= max_iter || rel < eps) break;
