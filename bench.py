@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--dense-variant", type=int, default=-1)
     ap.add_argument("--ingest-variant", type=int, default=-1)
     ap.add_argument("--roofline-reps", type=int, default=5)
+    ap.add_argument("--fisheye", action="store_true", help="BASELINE.json configs[3]-style run: fisheye model (use with --width 3840 --height 2160 --batch 256)")
     return ap.parse_args()
 
 
@@ -61,6 +62,8 @@ def main():
 
     cfg = api.default_config()
     abi.set_geometry(cfg, a.width, a.height, abi.RCC_PIX_BGR8)
+    if a.fisheye:
+        abi.set_distortion(cfg, abi.RCC_DIST_FISHEYE, abi.FISHEYE_DEFAULT)
     cfg.device = local
     cfg.batch_capacity = a.batch
     det = api.Detector(cfg)
@@ -110,13 +113,13 @@ def main():
     if rank == 0:
         fps = world * B * a.steps / dt
         out = {
-            "metric": "calibration frames/sec at 1920x1080", "value": fps, "unit": "frames/s",
+            "metric": "calibration frames/sec at %dx%d" % (a.width, a.height), "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i32 pixel stages, f64 sub-pixel + PnP", "data": "synthetic",
             "config": {"workload": "batch of %d synthetic %dx%d BGR8 checkerboard frames per GPU, device-resident "
                                    "(BASELINE.json configs[1]); corners + PnP" % (B, a.width, a.height),
-                       "frames_per_step_per_gpu": B, "board": "8x6 inner corners, 0.108 m", "distortion": "plumb-bob, undistort on",
+                       "frames_per_step_per_gpu": B, "board": "8x6 inner corners, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
                        "parallelism": "frame-sharded, 1 process per GPU, 1 all_gather of pose records per step"},
             "boards_found_in_last_step": int(found), "stage_ms_last_step": timings,
         }
@@ -135,7 +138,7 @@ def main():
         ach = alg / (ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_dense.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (a.width, a.height) == (1920, 1080):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_frame") * B   # PMC-derived, per frame x frames per launch
             except Exception:

@@ -337,3 +337,16 @@ def test_pnp_mappings_agree(torch_cuda, oracle):
     print("max |gpu - oracle| over 40 board solves, both mappings:", worst)
     assert worst <= TOL
     det.close()
+
+
+def test_config4_fisheye_4k(torch_cuda, oracle):
+    """BASELINE.json configs[3]: 3840x2160 frames with the fisheye model (stresses the undistortion
+    pass).  Whole path against the oracle: integer stages bit-exact, corners/pose within 1e-4."""
+    def mod(c):
+        abi.set_distortion(c, abi.RCC_DIST_FISHEYE, abi.FISHEYE_DEFAULT)
+    cfg = _make(mod, w=3840, h=2160, B=2)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch_cuda, det, cfg, 2, seed=404)
+    det.close()
+    mx, found = _check_batch(torch_cuda, oracle, cfg, frames, 2)
+    print("max diffs", mx)
