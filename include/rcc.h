@@ -64,6 +64,7 @@ enum {
 };
 
 #define RCC_MAX_BOARD_CORNERS 256
+#define RCC_MAX_KEPT_FIDUCIAL 2048   /* max_kept upper bound for RCC_TARGET_FIDUCIAL (256 for the board) */
 
 /* ---- configuration (POD) ------------------------------------------------------------------- */
 typedef struct rcc_config {
@@ -115,7 +116,17 @@ typedef struct rcc_config {
   /* resources */
   int32_t device;           /* HIP device ordinal */
   int32_t batch_capacity;   /* max frames per rcc_detect_batch call */
-  int32_t reserved[8];
+  /* a6, fiducial targets (RCC_TARGET_FIDUCIAL): square tags of 8x8 cells -- a one-cell black border
+   * around a 6x6 payload (white = 1), code word = payload row-major, MSB first.  The family table is
+   * DATA supplied by the caller (the tag36h11 table is not redistributable from memory);
+   * a build-generated family ships in robot_camera_calibration_amd/data/. */
+  int32_t family_n;              /* number of codes */
+  int32_t tag_max_hamming;       /* accept a decode with at most this many payload bit errors (2) */
+  const uint64_t* family_codes;  /* host pointer to family_n code words; copied at rcc_create */
+  double  tag_size;              /* metres, side of the black square: the four reported corners are its
+                                    corners and the object points are (+-tag_size/2, +-tag_size/2, 0)
+                                    (camera_pose.cpp:158-161) */
+  int32_t reserved[2];
 } rcc_config;
 
 /* ---- result records (POD) ------------------------------------------------------------------ */
@@ -244,7 +255,9 @@ typedef struct rcc_synth_params {
   double   noise_sigma;             /* additive Gaussian noise, LSB (2) */
   uint64_t seed;                    /* frame f uses seed + f (0xC0FFEE) */
   int32_t  black, white, background;/* 20, 235, 128 */
-  int32_t  reserved[5];
+  int32_t  fid_grid_x, fid_grid_y;  /* > 0: render a planar grid of fiducials (ids 0..) instead of the board */
+  int32_t  fid_gap_permille;        /* white gap between tags, in 1/1000 of the tag size (500) */
+  int32_t  reserved[2];
 } rcc_synth_params;
 
 /* Render nframes frames of the handle's geometry/intrinsics into d_frames (device), one pose per

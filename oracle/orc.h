@@ -65,6 +65,14 @@ int orc_validate_refined(const orc_cand* pre, int n, const double* xy, const uin
  * row-major board order. returns 1 if the board was found */
 int orc_grid_index(const orc_cand* pts, int n, int cols, int rows, int32_t* order_out);
 
+/* ---- a4/a6 square-fiducial form (orc_fiducial.c) ---- */
+int orc_fid_corner_class(const uint8_t* g, int w, int h, int x, int y, int min_contrast, int d1[2], int d2[2], int* thr);
+int orc_fid_homography(const double q[8], double H[9]);
+int orc_fid_decode(const uint8_t* g, int w, int h, const double q[8], const uint64_t* codes, int ncodes,
+                   int max_hamming, int* id_out, int* ham_out, int* rot_out);
+int orc_fid_detect(const uint8_t* grey, int w, int h, int min_contrast, const orc_cand* pre, const double* xy,
+                   int n, const uint64_t* codes, int ncodes, int max_hamming, rcc_detection* out, int cap);
+
 /* ---- a7 / a8 pose ---- */
 void orc_rodrigues_v2m(const double r[3], double R[9], double J[27]);  /* J: 3x9, may be NULL */
 void orc_rodrigues_m2v(const double R[9], double r[3]);

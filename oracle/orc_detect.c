@@ -22,13 +22,14 @@ typedef struct orc_ctx {
   orc_cand* cand;
   orc_cand* pre;
   orc_cand* kept;
+  double* pxy;
 } orc_ctx;
 
 void orc_ctx_destroy(orc_ctx* c)
 {
   if (!c) return;
   free(c->mapx); free(c->mapy); free(c->tmp); free(c->grey); free(c->bin); free(c->R);
-  free(c->cand); free(c->pre); free(c->kept);
+  free(c->cand); free(c->pre); free(c->kept); free(c->pxy);
   free(c);
 }
 
@@ -43,14 +44,15 @@ orc_ctx* orc_ctx_create(const rcc_config* cfg)
   c->bin = (uint8_t*)malloc(n);
   c->R = (int32_t*)malloc(n * sizeof(int32_t));
   c->cand = (orc_cand*)malloc(sizeof(orc_cand) * (size_t)(cfg->max_candidates > 0 ? cfg->max_candidates : 1));
-  c->pre = (orc_cand*)malloc(sizeof(orc_cand) * 256);
+  c->pre = (orc_cand*)malloc(sizeof(orc_cand) * RCC_MAX_KEPT_FIDUCIAL);
   c->kept = (orc_cand*)malloc(sizeof(orc_cand) * 256);
+  c->pxy = (double*)malloc(sizeof(double) * 2 * RCC_MAX_KEPT_FIDUCIAL);
   if (cfg->undistort && cfg->dist_model != RCC_DIST_NONE) {
     c->mapx = (int32_t*)malloc(n * sizeof(int32_t));
     c->mapy = (int32_t*)malloc(n * sizeof(int32_t));
     if (c->mapx && c->mapy) orc_undistort_map_q5(cfg->K, cfg->dist_model, cfg->D, cfg->width, cfg->height, c->mapx, c->mapy);
   }
-  if (!c->tmp || !c->grey || !c->bin || !c->R || !c->cand || !c->pre || !c->kept) { orc_ctx_destroy(c); return NULL; }
+  if (!c->tmp || !c->grey || !c->bin || !c->R || !c->cand || !c->pre || !c->kept || !c->pxy) { orc_ctx_destroy(c); return NULL; }
   return c;
 }
 
@@ -74,7 +76,8 @@ int orc_ctx_detect(orc_ctx* c, const uint8_t* frame, int frame_index, rcc_detect
   rcc_frame_corners fcl;
   rcc_frame_corners* fc = fc_out ? fc_out : &fcl;
   memset(fc, 0, sizeof(*fc));
-  const int max_kept = cfg->max_kept < 256 ? cfg->max_kept : 256;
+  const int kept_lim = (cfg->target_kind == RCC_TARGET_FIDUCIAL) ? RCC_MAX_KEPT_FIDUCIAL : 256;
+  const int max_kept = cfg->max_kept < kept_lim ? cfg->max_kept : kept_lim;
 
   ingest(c, frame);
   orc_threshold_tiles(c->grey, w, h, cfg->thr_min_contrast, c->bin);
@@ -94,9 +97,41 @@ int orc_ctx_detect(orc_ctx* c, const uint8_t* frame, int frame_index, rcc_detect
   if (npre_out) *npre_out = npre;
   if (npre > max_kept) { fc->status = RCC_FRAME_KEPT_OVERFLOW; return 0; }
   if (pre_out) memcpy(pre_out, c->pre, sizeof(orc_cand) * (size_t)npre);
-  double pxy[2 * 256], xy[2 * 256];
+  double* pxy = c->pxy;
+  double xy[2 * 256];
   orc_corner_subpix(c->grey, w, h, c->pre, npre, cfg->subpix_win, cfg->subpix_max_iter, cfg->subpix_eps, pxy);
   if (pre_xy_out) memcpy(pre_xy_out, pxy, sizeof(double) * 2 * (size_t)npre);
+  if (cfg->target_kind == RCC_TARGET_FIDUCIAL) {
+    /* a4/a6 square-fiducial form + a7 per tag (4 corners bl,br,tr,tl; camera_pose.cpp:152-163) */
+    const int cap = cfg->max_targets;
+    rcc_detection* tmp = (rcc_detection*)malloc(sizeof(rcc_detection) * (size_t)(cap > 0 ? cap : 1));
+    int m = orc_fid_detect(c->grey, w, h, cfg->thr_min_contrast, c->pre, pxy, npre, cfg->family_codes, cfg->family_n,
+                           cfg->tag_max_hamming, tmp, cap);
+    if (m > cap) m = cap;
+    const double s2 = 0.5 * cfg->tag_size;
+    const double obj[12] = { -s2, -s2, 0, s2, -s2, 0, s2, s2, 0, -s2, s2, 0 };
+    const int undist = cfg->undistort && cfg->dist_model != RCC_DIST_NONE;
+    for (int k = 0; k < m; ++k) {
+      rcc_detection* d = tmp + k;
+      d->frame = frame_index;
+      d->size = cfg->tag_size;
+      double img[8];
+      for (int q = 0; q < 4; ++q) {
+        double x = d->corners[q][0], y = d->corners[q][1];
+        if (cfg->reference_mode) { x = (double)(int)x; y = (double)(int)y; }
+        img[2 * q] = x; img[2 * q + 1] = y;
+      }
+      int iters = 0;
+      d->pnp_status = orc_solve_pnp(obj, img, 4, cfg->K, undist ? RCC_DIST_NONE : cfg->dist_model, cfg->D,
+                                    d->rvec, d->tvec, &d->rms, &iters);
+      d->pnp_iters = iters;
+      if (det) det[k] = *d;
+    }
+    free(tmp);
+    fc->nkept = npre;
+    if (m == 0) fc->status = RCC_FRAME_NOT_FOUND;
+    return m;
+  }
   int nkept = orc_validate_refined(c->pre, npre, pxy, c->bin, w, h, cfg->xj_check, 2, c->kept, xy, max_kept);
   fc->nkept = nkept;
   if (nkept_out) *nkept_out = nkept;
@@ -170,10 +205,10 @@ int orc_ctx_detect_many(orc_ctx* c, const uint8_t* frames, int64_t frame_bytes, 
 {
   int found = 0;
   for (int f = 0; f < nframes; ++f) {
-    rcc_detection d;
-    int r = orc_ctx_detect(c, frames + (size_t)f * frame_bytes, f, &d, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+    rcc_detection d[64];
+    int r = orc_ctx_detect(c, frames + (size_t)f * frame_bytes, f, c->cfg.max_targets <= 64 ? d : NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
     if (r > 0) {
-      if (det_out) det_out[found] = d;
+      if (det_out && c->cfg.max_targets <= 64) det_out[found] = d[0];
       ++found;
     }
   }

@@ -256,24 +256,26 @@ class Context:
     def detect(self, frame, frame_index=0, stages=False):
         cfg = self.cfg
         frame = np.ascontiguousarray(frame, np.uint8)
-        det = abi.rcc_detection()
+        multi = cfg.target_kind == abi.RCC_TARGET_FIDUCIAL
+        det = (abi.rcc_detection * max(cfg.max_targets, 1))() if multi else abi.rcc_detection()
+        dref = det if multi else C.byref(det)
         fc = abi.rcc_frame_corners()
         if stages:
             grey = np.empty((cfg.height, cfg.width), np.uint8)
             binm = np.empty((cfg.height, cfg.width), np.uint8)
             cand = np.zeros(cfg.max_candidates, CAND_DT)
             kept = np.zeros(256, CAND_DT)
-            pre = np.zeros(256, CAND_DT)
-            pre_xy = np.zeros((256, 2))
+            pre = np.zeros(abi.RCC_MAX_KEPT_FIDUCIAL, CAND_DT)
+            pre_xy = np.zeros((abi.RCC_MAX_KEPT_FIDUCIAL, 2))
             nc = C.c_int32(0)
             nk = C.c_int32(0)
             npre = C.c_int32(0)
-            n = lib().orc_ctx_detect(self._c, _p(frame), frame_index, C.byref(det), C.byref(fc), _p(grey), _p(binm), _p(cand), C.byref(nc),
+            n = lib().orc_ctx_detect(self._c, _p(frame), frame_index, dref, C.byref(fc), _p(grey), _p(binm), _p(cand), C.byref(nc),
                                      _p(pre), C.byref(npre), _p(pre_xy), _p(kept), C.byref(nk))
             return n, det, fc, dict(grey=grey, bin=binm, cand=cand[:min(nc.value, cfg.max_candidates)], ncand=nc.value,
-                                    pre=pre[:min(npre.value, 256)], npre=npre.value, pre_xy=pre_xy[:min(npre.value, 256)],
+                                    pre=pre[:min(npre.value, abi.RCC_MAX_KEPT_FIDUCIAL)], npre=npre.value, pre_xy=pre_xy[:min(npre.value, abi.RCC_MAX_KEPT_FIDUCIAL)],
                                     kept=kept[:min(nk.value, 256)], nkept=nk.value)
-        n = lib().orc_ctx_detect(self._c, _p(frame), frame_index, C.byref(det), C.byref(fc), None, None, None, None, None, None, None, None, None)
+        n = lib().orc_ctx_detect(self._c, _p(frame), frame_index, dref, C.byref(fc), None, None, None, None, None, None, None, None, None)
         return n, det, fc
 
     def detect_many(self, frames, nframes):

@@ -85,6 +85,10 @@ void orc_synth_render(const rcc_config* cfg, const rcc_synth_params* sp, const d
   inv3(H, Hi);
   const int ss = sp->supersample < 1 ? 1 : sp->supersample;
   const double sq = sp->board_square;
+  const int fid = sp->fid_grid_x > 0 && sp->fid_grid_y > 0;       /* planar grid of fiducials instead of the board */
+  const double tag = cfg->tag_size, pitch = tag * (1.0 + 0.001 * sp->fid_gap_permille);
+  const double fhx = 0.5 * (sp->fid_grid_x * pitch - (pitch - tag)) + 0.5 * tag;   /* half extent incl. half-tag quiet zone */
+  const double fhy = 0.5 * (sp->fid_grid_y * pitch - (pitch - tag)) + 0.5 * tag;
   const int nsx = sp->board_cols + 1, nsy = sp->board_rows + 1;   /* squares */
   const double hx = 0.5 * nsx, hy = 0.5 * nsy;                   /* half extents in squares */
   const double mg = (double)sp->margin_squares;
@@ -106,7 +110,26 @@ void orc_synth_render(const rcc_config* cfg, const rcc_synth_params* sp, const d
             double q0 = Hi[0] * x + Hi[1] * y + Hi[2];
             double q1 = Hi[3] * x + Hi[4] * y + Hi[5];
             double q2 = Hi[6] * x + Hi[7] * y + Hi[8];
-            if (q2 > 0.0) {
+            if (q2 > 0.0 && fid) {
+              /* metres on the tag plane, x right, y up (object frame of camera_pose.cpp:158-161) */
+              const double Xm = q0 / q2, Ym = q1 / q2;
+              if (fabs(Xm) < fhx && fabs(Ym) < fhy) {
+                cls = 1;
+                const double gx = (Xm + fhx - 0.5 * tag) / pitch, gy = (fhy - 0.5 * tag - Ym) / pitch;   /* grid coords, row 0 on top */
+                const int ti = (int)floor(gx), tj = (int)floor(gy);
+                if (ti >= 0 && tj >= 0 && ti < sp->fid_grid_x && tj < sp->fid_grid_y) {
+                  const double u = (gx - ti) * pitch / tag * 8.0, v = (gy - tj) * pitch / tag * 8.0;   /* cells */
+                  if (u < 8.0 && v < 8.0) {
+                    const int cu = (int)floor(u), cv = (int)floor(v);
+                    if (cu == 0 || cv == 0 || cu == 7 || cv == 7) cls = 2;
+                    else {
+                      const uint64_t code = cfg->family_codes[(tj * sp->fid_grid_x + ti) % cfg->family_n];
+                      cls = ((code >> (35 - ((cv - 1) * 6 + (cu - 1)))) & 1u) ? 1 : 2;
+                    }
+                  }
+                }
+              }
+            } else if (q2 > 0.0) {
               double X = q0 / q2 / sq, Y = q1 / q2 / sq;   /* in squares, origin at the centre */
               if (fabs(X) < hx + mg && fabs(Y) < hy + mg) {
                 cls = 1;

@@ -38,7 +38,10 @@ class rcc_config(C.Structure):
         ("board_id", C.c_int32), ("max_targets", C.c_int32),
         ("reference_mode", C.c_int32), ("pnp_use_mfma", C.c_int32),
         ("device", C.c_int32), ("batch_capacity", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("family_n", C.c_int32), ("tag_max_hamming", C.c_int32),
+        ("family_codes", C.c_void_p),
+        ("tag_size", C.c_double),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -70,7 +73,8 @@ class rcc_synth_params(C.Structure):
         ("noise_sigma", C.c_double),
         ("seed", C.c_uint64),
         ("black", C.c_int32), ("white", C.c_int32), ("background", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("fid_grid_x", C.c_int32), ("fid_grid_y", C.c_int32), ("fid_gap_permille", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -113,3 +117,31 @@ def set_distortion(cfg, model, coeffs):
 
 PLUMB_BOB_DEFAULT = (-0.28, 0.07, 2e-4, -1e-4, 0.0)
 FISHEYE_DEFAULT = (-0.02, 0.005, -0.001, 0.0002)
+
+
+RCC_MAX_KEPT_FIDUCIAL = 2048
+_FAMILY_CACHE = {}
+
+
+def load_family(name="family36b"):
+    """The build-generated 36-bit family (data/family36b.txt, made by data/make_family.py): numpy
+    uint64 array.  Keep the array alive while a config points at it."""
+    import os
+    import numpy as np
+    if name not in _FAMILY_CACHE:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", name + ".txt")
+        _FAMILY_CACHE[name] = np.array([int(l, 16) for l in open(path) if l.strip() and not l.startswith("#")], dtype=np.uint64)
+    return _FAMILY_CACHE[name]
+
+
+def set_fiducial_target(cfg, family, tag_size=0.10, max_hamming=2, max_targets=64, max_kept=2048):
+    cfg.target_kind = RCC_TARGET_FIDUCIAL
+    cfg.family_n = len(family)
+    cfg.family_codes = family.ctypes.data
+    cfg.tag_size = tag_size
+    cfg.tag_max_hamming = max_hamming
+    cfg.max_targets = max_targets
+    cfg.max_kept = max_kept
+    cfg.max_candidates = 4096
+    cfg.xj_check = 0
+    return cfg

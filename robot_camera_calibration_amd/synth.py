@@ -77,7 +77,7 @@ def project_points(obj, rvec, tvec, K, model=abi.RCC_DIST_NONE, D=(0,) * 8):
 
 
 def sample_poses(n, cfg, seed=0xC0FFEE, z_range=(0.8, 2.5), max_tilt_deg=45.0, max_roll_deg=180.0,
-                 border_px=14, margin_squares=1, first_index=0):
+                 border_px=14, margin_squares=1, first_index=0, half_extent_m=None):
     """Deterministic per-frame poses (cam_T_target as rvec,tvec): frame f is drawn from
     default_rng(seed + f).  Rejection-samples until the board plus its quiet zone projects fully
     inside the (distorted) image.  Returns an (n, 6) float64 array."""
@@ -87,6 +87,8 @@ def sample_poses(n, cfg, seed=0xC0FFEE, z_range=(0.8, 2.5), max_tilt_deg=45.0, m
     cols, rows, sq = cfg.board_cols, cfg.board_rows, cfg.board_square
     hx = (cols + 1) / 2.0 + margin_squares
     hy = (rows + 1) / 2.0 + margin_squares
+    if half_extent_m is not None:      # a planar target of arbitrary size (e.g. a fiducial grid)
+        hx, hy, sq = half_extent_m[0], half_extent_m[1], 1.0
     outline = []
     for t in np.linspace(-1, 1, 9):
         outline += [(t * hx * sq, -hy * sq, 0), (t * hx * sq, hy * sq, 0), (-hx * sq, t * hy * sq, 0), (hx * sq, t * hy * sq, 0)]
@@ -120,3 +122,24 @@ def sample_poses(n, cfg, seed=0xC0FFEE, z_range=(0.8, 2.5), max_tilt_deg=45.0, m
         else:
             raise RuntimeError("could not place the board in view for frame %d" % f)
     return out
+
+
+def fiducial_grid_layout(gx, gy, tag_size, gap_permille=500):
+    """Planar grid of square fiducials as k_synth renders it: returns (half_extent (hx, hy) in
+    metres incl. the half-tag quiet zone, centres (gy*gx, 3) of the tags in the plane frame
+    (x right, y up), ids).  Tag (i, j) = column i, row j (row 0 on top) has id j*gx+i."""
+    pitch = tag_size * (1.0 + gap_permille / 1000.0)
+    hx = 0.5 * (gx * pitch - (pitch - tag_size)) + 0.5 * tag_size
+    hy = 0.5 * (gy * pitch - (pitch - tag_size)) + 0.5 * tag_size
+    cs, ids = [], []
+    for j in range(gy):
+        for i in range(gx):
+            cs.append([-hx + 0.5 * tag_size + i * pitch + 0.5 * tag_size, hy - 0.5 * tag_size - j * pitch - 0.5 * tag_size, 0.0])
+            ids.append(j * gx + i)
+    return (hx, hy), np.array(cs), np.array(ids)
+
+
+def tag_object_points(tag_size):
+    """bl, br, tr, tl in the tag frame (real_preprocessing/src/camera_pose.cpp:158-161)"""
+    s = tag_size / 2.0
+    return np.array([[-s, -s, 0], [s, -s, 0], [s, s, 0], [-s, s, 0]], float)
