@@ -275,9 +275,10 @@ class Detector:
 
     # ---- test taps ---------------------------------------------------------------------------------
     def fetch_lists(self, nframes):
-        pre = np.zeros((nframes, 256), CAND_DT); kept = np.zeros((nframes, 256), CAND_DT)
+        kc = abi.RCC_MAX_KEPT_FIDUCIAL if self.cfg.target_kind == abi.RCC_TARGET_FIDUCIAL else 256
+        pre = np.zeros((nframes, kc), CAND_DT); kept = np.zeros((nframes, 256), CAND_DT)
         npre = np.zeros(nframes, np.int32)
-        pre_xy = np.zeros((nframes, 256, 2)); kept_xy = np.zeros((nframes, 256, 2))
+        pre_xy = np.zeros((nframes, kc, 2)); kept_xy = np.zeros((nframes, 256, 2))
         self._chk(self._L.rcc_debug_fetch_lists(self._h, nframes, _ptr(pre), _ptr(npre), _ptr(pre_xy), _ptr(kept), _ptr(kept_xy)),
                   "rcc_debug_fetch_lists")
         return dict(pre=pre, npre=npre, pre_xy=pre_xy, kept=kept, kept_xy=kept_xy)

@@ -12,7 +12,7 @@
 
 __global__ __launch_bounds__(256) void k_list_sort_nms(const rcc_cand* __restrict__ cand,
                                                        const int32_t* __restrict__ cand_count, int cap,
-                                                       int nms_radius, int max_kept,
+                                                       int nms_radius, int max_kept, int kstride,
                                                        rcc_cand* __restrict__ pre, int32_t* __restrict__ npre,
                                                        rcc_frame_corners* __restrict__ fc)
 {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_list_sort_nms(const rcc_cand* __restric
   }
   int o = s_off[tid];
   for (int i = i0; i < i1; ++i)
-    if (raw[i].x) pre[(size_t)f * RCC_MAX_KEPT + o++] = srt[i];
+    if (raw[i].x) pre[(size_t)f * kstride + o++] = srt[i];
   if (tid == 0) npre[f] = total;
 }
 
@@ -93,8 +93,8 @@ hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t*
 {
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
-  int max_kept = c.max_kept < RCC_MAX_KEPT ? c.max_kept : RCC_MAX_KEPT;
+  int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
   hipLaunchKernelGGL(k_list_sort_nms, dim3(nframes), dim3(256), 0, s, d_cand, d_cand_count,
-                     c.max_candidates, c.nms_radius, max_kept, h->d_pre, h->d_npre, h->d_fc);
+                     c.max_candidates, c.nms_radius, max_kept, h->kept_cap, h->d_pre, h->d_npre, h->d_fc);
   return hipGetLastError();
 }

@@ -24,14 +24,14 @@ __device__ __forceinline__ double wave_tree_sum(double v)
 // grid (ceil(max_kept), nframes): block b handles candidate blockIdx.x of frame blockIdx.y
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                               rcc_subpix_params sp, double* __restrict__ pre_xy)
+                                               rcc_subpix_params sp, int kstride, double* __restrict__ pre_xy)
 {
   __shared__ double S[SP_MAXP * SP_MAXP];
   const int f = blockIdx.y, q = blockIdx.x;
   if (q >= npre[f]) return;
   const int lane = threadIdx.x;
   const uint8_t* g = grey + (size_t)f * w * h;
-  const rcc_cand c0 = pre[(size_t)f * RCC_MAX_KEPT + q];
+  const rcc_cand c0 = pre[(size_t)f * kstride + q];
   const int win = sp.win;
   const int ww = 2 * win + 1, pw = 2 * win + 3;
   const double x0 = (double)c0.x, y0 = (double)c0.y;
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   } while (++iter < sp.max_iter && err > sp.eps2);
   if (bad || fabs(cx - x0) > (double)win || fabs(cy - y0) > (double)win) { cx = x0; cy = y0; }
   if (lane == 0) {
-    pre_xy[((size_t)f * RCC_MAX_KEPT + q) * 2] = cx;
-    pre_xy[((size_t)f * RCC_MAX_KEPT + q) * 2 + 1] = cy;
+    pre_xy[((size_t)f * kstride + q) * 2] = cx;
+    pre_xy[((size_t)f * kstride + q) * 2 + 1] = cy;
   }
 }
 
@@ -113,8 +113,8 @@ hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, 
 {
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
-  int max_kept = c.max_kept < RCC_MAX_KEPT ? c.max_kept : RCC_MAX_KEPT;
+  int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
   hipLaunchKernelGGL(k_subpix, dim3(max_kept, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
-                     h->d_pre, h->d_npre, h->sp, h->d_pre_xy);
+                     h->d_pre, h->d_npre, h->sp, h->kept_cap, h->d_pre_xy);
   return hipGetLastError();
 }

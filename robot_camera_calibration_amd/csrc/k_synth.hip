@@ -67,6 +67,9 @@ struct synth_args {
   int base[3];
   uint64_t seed;
   int first_index;
+  int fid_gx, fid_gy, family_n;
+  double tag, pitch;
+  const uint64_t* codes;
 };
 
 __global__ __launch_bounds__(256) void k_synth_render(synth_args a, const double* __restrict__ hinv, uint8_t* __restrict__ frames)
@@ -77,6 +80,9 @@ __global__ __launch_bounds__(256) void k_synth_render(synth_args a, const double
   if (u >= a.w || v >= a.h) return;
   const double* Hi = hinv + 9 * (size_t)f;
   const double hx = 0.5 * a.nsx, hy = 0.5 * a.nsy, mg = (double)a.margin;
+  const bool fid = a.fid_gx > 0 && a.fid_gy > 0;
+  const double fhx = 0.5 * (a.fid_gx * a.pitch - (a.pitch - a.tag)) + 0.5 * a.tag;
+  const double fhy = 0.5 * (a.fid_gy * a.pitch - (a.pitch - a.tag)) + 0.5 * a.tag;
   const int tint[3][3] = { { 10, 0, -10 }, { -8, 0, -3 }, { 4, 0, 2 } };
   double acc[3] = { 0, 0, 0 };
   for (int sy = 0; sy < a.ss; ++sy)
@@ -89,7 +95,25 @@ __global__ __launch_bounds__(256) void k_synth_render(synth_args a, const double
         double q0 = Hi[0] * x + Hi[1] * y + Hi[2];
         double q1 = Hi[3] * x + Hi[4] * y + Hi[5];
         double q2 = Hi[6] * x + Hi[7] * y + Hi[8];
-        if (q2 > 0.0) {
+        if (q2 > 0.0 && fid) {
+          const double Xm = q0 / q2, Ym = q1 / q2;
+          if (fabs(Xm) < fhx && fabs(Ym) < fhy) {
+            cls = 1;
+            const double gx = (Xm + fhx - 0.5 * a.tag) / a.pitch, gy = (fhy - 0.5 * a.tag - Ym) / a.pitch;
+            const int ti = (int)floor(gx), tj = (int)floor(gy);
+            if (ti >= 0 && tj >= 0 && ti < a.fid_gx && tj < a.fid_gy) {
+              const double uu = (gx - ti) * a.pitch / a.tag * 8.0, vv = (gy - tj) * a.pitch / a.tag * 8.0;
+              if (uu < 8.0 && vv < 8.0) {
+                const int cu = (int)floor(uu), cv = (int)floor(vv);
+                if (cu == 0 || cv == 0 || cu == 7 || cv == 7) cls = 2;
+                else {
+                  const uint64_t code = a.codes[(tj * a.fid_gx + ti) % a.family_n];
+                  cls = ((code >> (35 - ((cv - 1) * 6 + (cu - 1)))) & 1u) ? 1 : 2;
+                }
+              }
+            }
+          }
+        } else if (q2 > 0.0) {
           double X = q0 / q2 / a.sq, Y = q1 / q2 / a.sq;
           if (fabs(X) < hx + mg && fabs(Y) < hy + mg) {
             cls = 1;
@@ -133,6 +157,11 @@ hipError_t rcc_launch_synth(rcc_handle* h, const rcc_synth_params* sp, const dou
   a.base[0] = sp->background; a.base[1] = sp->white; a.base[2] = sp->black;
   a.seed = sp->seed;
   a.first_index = first_index;
+  a.fid_gx = a.fid_gy = 0; a.family_n = 1; a.tag = 1.0; a.pitch = 1.5; a.codes = nullptr;
+  if (sp->fid_grid_x > 0 && sp->fid_grid_y > 0 && h->d_family) {
+    a.fid_gx = sp->fid_grid_x; a.fid_gy = sp->fid_grid_y; a.family_n = c.family_n;
+    a.tag = c.tag_size; a.pitch = c.tag_size * (1.0 + 0.001 * sp->fid_gap_permille); a.codes = h->d_family;
+  }
   dim3 grid((c.width + 63) / 64, (c.height + 3) / 4, nframes), block(64, 4);
   hipLaunchKernelGGL(k_synth_render, grid, block, 0, s, a, d_hinv, d_frames);
   return hipGetLastError();

@@ -87,7 +87,7 @@ static int validate(const rcc_config* c)
   if (c->dist_model < RCC_DIST_NONE || c->dist_model > RCC_DIST_FISHEYE) return RCC_ERR_ARG;
   if (!(c->K[0] > 0.0) || !(c->K[4] > 0.0)) return RCC_ERR_ARG;
   if (c->max_candidates < 1 || c->max_candidates > 4096) return RCC_ERR_ARG;
-  if (c->max_kept < 1 || c->max_kept > RCC_MAX_KEPT) return RCC_ERR_ARG;
+  if (c->max_kept < 1 || (c->target_kind != RCC_TARGET_FIDUCIAL && c->max_kept > RCC_MAX_KEPT)) return RCC_ERR_ARG;
   if (c->subpix_win < 1 || c->subpix_win > 7 || c->subpix_max_iter < 1) return RCC_ERR_ARG;
   if (c->nms_radius < 0 || c->cand_margin < 0) return RCC_ERR_ARG;
   if (c->batch_capacity < 1) return RCC_ERR_ARG;
@@ -96,7 +96,9 @@ static int validate(const rcc_config* c)
     if (c->board_cols < 2 || c->board_rows < 2 || c->board_cols > 16 || c->board_rows > 16) return RCC_ERR_ARG;
     if (c->board_cols * c->board_rows > RCC_MAX_BOARD_CORNERS || !(c->board_square > 0.0)) return RCC_ERR_ARG;
   } else if (c->target_kind == RCC_TARGET_FIDUCIAL) {
-    return RCC_ERR_UNSUPPORTED;   // multi-fiducial path: SURVEY 8(a) a4/a6 second form, not in this round
+    if (!c->family_codes || c->family_n < 1 || c->family_n > 65536 || !(c->tag_size > 0.0)) return RCC_ERR_ARG;
+    if (c->tag_max_hamming < 0 || c->tag_max_hamming > 8 || c->max_targets > 4096) return RCC_ERR_ARG;
+    if (c->max_kept > RCC_MAX_KEPT_FIDUCIAL) return RCC_ERR_ARG;
   } else {
     return RCC_ERR_ARG;
   }
@@ -113,7 +115,7 @@ void rcc_destroy(rcc_handle* h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = { h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
                    h->d_kept, h->d_kept_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
-                   h->d_board_obj, h->d_img_scratch };
+                   h->d_board_obj, h->d_img_scratch, h->d_family };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_det) (void)hipHostFree(h->h_det);
   if (h->h_ndet) (void)hipHostFree(h->h_ndet);
@@ -139,6 +141,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->dense_variant = -1;
   h->ingest_variant = -1;
   h->pnp_variant = -1;
+  h->kept_cap = (cfg->target_kind == RCC_TARGET_FIDUCIAL) ? RCC_MAX_KEPT_FIDUCIAL : RCC_MAX_KEPT;
   h->pnp_solver = 1;
   if (const char* e = getenv("RCC_PNP_SOLVER")) h->pnp_solver = atoi(e);
   h->sp.win = cfg->subpix_win;
@@ -161,9 +164,9 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   ALLOC(h->d_bin, B * px);
   ALLOC(h->d_cand, B * (size_t)cfg->max_candidates * sizeof(rcc_cand));
   ALLOC(h->d_cand_count, B * sizeof(int32_t));
-  ALLOC(h->d_pre, B * RCC_MAX_KEPT * sizeof(rcc_cand));
+  ALLOC(h->d_pre, B * (size_t)h->kept_cap * sizeof(rcc_cand));
   ALLOC(h->d_npre, B * sizeof(int32_t));
-  ALLOC(h->d_pre_xy, B * RCC_MAX_KEPT * 2 * sizeof(double));
+  ALLOC(h->d_pre_xy, B * (size_t)h->kept_cap * 2 * sizeof(double));
   ALLOC(h->d_kept, B * RCC_MAX_KEPT * sizeof(rcc_cand));
   ALLOC(h->d_kept_xy, B * RCC_MAX_KEPT * 2 * sizeof(double));
   ALLOC(h->d_fc, B * sizeof(rcc_frame_corners));
@@ -188,6 +191,14 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
       rcc_destroy(h);
       return RCC_ERR_DEVICE;
     }
+  }
+  if (cfg->target_kind == RCC_TARGET_FIDUCIAL) {
+    ALLOC(h->d_family, (size_t)cfg->family_n * sizeof(uint64_t));
+    if (hipMemcpy(h->d_family, cfg->family_codes, (size_t)cfg->family_n * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
+      rcc_destroy(h);
+      return RCC_ERR_DEVICE;
+    }
+    h->cfg.family_codes = nullptr;   // the caller's table is not referenced after create
   }
   *out = h;
   return RCC_OK;
@@ -283,24 +294,30 @@ static int run_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bi
                        const int32_t* d_cand_count, int nframes, rcc_detection* det, int32_t* ndet,
                        rcc_frame_corners* corners, hipStream_t s)
 {
+  const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
+  const int slots = h->cfg.max_targets;
   HIPCHK(h, hipEventRecord(h->ev[2], s));
   HIPCHK(h, rcc_launch_list(h, d_cand, d_cand_count, nframes, s));
   HIPCHK(h, rcc_launch_subpix(h, d_grey, nframes, s));
-  HIPCHK(h, rcc_launch_grid(h, d_bin, nframes, s));
+  if (fid) HIPCHK(h, rcc_launch_fid(h, d_grey, nframes, s));
+  else HIPCHK(h, rcc_launch_grid(h, d_bin, nframes, s));
   HIPCHK(h, hipEventRecord(h->ev[3], s));
-  HIPCHK(h, rcc_launch_pnp_board(h, nframes, s));
+  if (fid) HIPCHK(h, rcc_launch_pnp_tags(h, nframes, s));
+  else HIPCHK(h, rcc_launch_pnp_board(h, nframes, s));
   HIPCHK(h, hipEventRecord(h->ev[4], s));
-  HIPCHK(h, hipMemcpyAsync(h->h_det, h->d_det, sizeof(rcc_detection) * (size_t)nframes, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(h->h_det, h->d_det, sizeof(rcc_detection) * (size_t)nframes * (fid ? slots : 1), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->h_ndet, h->d_ndet, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost, s));
   if (corners) HIPCHK(h, hipMemcpyAsync(corners, h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipEventRecord(h->ev[5], s));
   HIPCHK(h, hipStreamSynchronize(s));
   int n = 0;
-  for (int f = 0; f < nframes; ++f)
-    if (h->h_ndet[f] > 0) {
-      if (det) det[n] = h->h_det[f];
+  for (int f = 0; f < nframes; ++f) {
+    const int k = h->h_ndet[f] < slots ? h->h_ndet[f] : slots;
+    for (int q = 0; q < k; ++q) {
+      if (det) det[n] = h->h_det[(size_t)f * (fid ? slots : 1) + q];
       ++n;
     }
+  }
   if (ndet) *ndet = n;
   (void)hipEventElapsedTime(&h->last_ms[2], h->ev[2], h->ev[3]);
   (void)hipEventElapsedTime(&h->last_ms[3], h->ev[3], h->ev[4]);
@@ -362,11 +379,12 @@ int rcc_debug_fetch_lists(rcc_handle* h, int32_t nframes, void* pre /*B*256 cand
   if (!h || nframes < 0 || nframes > h->cfg.batch_capacity) return RCC_ERR_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t n = (size_t)nframes;
-  if (pre) HIPCHK(h, hipMemcpy(pre, h->d_pre, n * RCC_MAX_KEPT * sizeof(rcc_cand), hipMemcpyDeviceToHost));
+  const size_t kc = (size_t)h->kept_cap;
+  if (pre) HIPCHK(h, hipMemcpy(pre, h->d_pre, n * kc * sizeof(rcc_cand), hipMemcpyDeviceToHost));
   if (npre) HIPCHK(h, hipMemcpy(npre, h->d_npre, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (pre_xy) HIPCHK(h, hipMemcpy(pre_xy, h->d_pre_xy, n * RCC_MAX_KEPT * 2 * sizeof(double), hipMemcpyDeviceToHost));
-  if (kept) HIPCHK(h, hipMemcpy(kept, h->d_kept, n * RCC_MAX_KEPT * sizeof(rcc_cand), hipMemcpyDeviceToHost));
-  if (kept_xy) HIPCHK(h, hipMemcpy(kept_xy, h->d_kept_xy, n * RCC_MAX_KEPT * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  if (pre_xy) HIPCHK(h, hipMemcpy(pre_xy, h->d_pre_xy, n * kc * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  if (kept && h->cfg.target_kind == RCC_TARGET_CHECKERBOARD) HIPCHK(h, hipMemcpy(kept, h->d_kept, n * RCC_MAX_KEPT * sizeof(rcc_cand), hipMemcpyDeviceToHost));
+  if (kept_xy && h->cfg.target_kind == RCC_TARGET_CHECKERBOARD) HIPCHK(h, hipMemcpy(kept_xy, h->d_kept_xy, n * RCC_MAX_KEPT * 2 * sizeof(double), hipMemcpyDeviceToHost));
   return RCC_OK;
 }
 int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin, void* cand, int32_t* cand_count)

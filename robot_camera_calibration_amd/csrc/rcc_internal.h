@@ -60,6 +60,8 @@ struct rcc_handle {
   int dense_variant, ingest_variant;
   int pnp_variant;          // -1 auto, 0 lane per target, 1 wavefront per target (board)
   int pnp_solver;           // 0 eigen, 1 Cholesky (default)
+  int kept_cap;             // stride of the per-frame suppressed-list buffers: 256 (board) or 2048 (fiducials)
+  uint64_t* d_family;       // fiducial family table (device copy)
   int pnp_wave_hint;        // set per rcc_solve_pnp_batch call: max points per target > 8
   rcc_subpix_params sp;
   char err[256];
@@ -73,6 +75,8 @@ hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t*
                            int nframes, hipStream_t s);
 hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);
 hipError_t rcc_launch_grid(rcc_handle* h, const uint8_t* d_bin, int nframes, hipStream_t s);
+hipError_t rcc_launch_fid(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);
+hipError_t rcc_launch_pnp_tags(rcc_handle* h, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_generic(rcc_handle* h, const double* d_obj, const double* d_img,
                                   const int32_t* d_off, const int32_t* d_npts, int ntargets,

@@ -66,8 +66,8 @@ def test_host_only_entry_points(built, oracle):
     assert built.rcc_create(None, C.byref(C.c_void_p())) == abi.RCC_ERR_ARG
     bad = api.default_config(); bad.struct_size = 12
     assert built.rcc_create(C.byref(bad), C.byref(C.c_void_p())) == abi.RCC_ERR_ARG
-    fid = api.default_config(); fid.target_kind = abi.RCC_TARGET_FIDUCIAL
-    assert built.rcc_create(C.byref(fid), C.byref(C.c_void_p())) == abi.RCC_ERR_UNSUPPORTED
+    fid = api.default_config(); fid.target_kind = abi.RCC_TARGET_FIDUCIAL      # no family table given
+    assert built.rcc_create(C.byref(fid), C.byref(C.c_void_p())) == abi.RCC_ERR_ARG
     fe = api.default_config(); fe.dist_model = abi.RCC_DIST_FISHEYE; fe.undistort = 0
     assert built.rcc_create(C.byref(fe), C.byref(C.c_void_p())) == abi.RCC_ERR_UNSUPPORTED
 
