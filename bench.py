@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--dense-variant", type=int, default=-1)
     ap.add_argument("--ingest-variant", type=int, default=-1)
     ap.add_argument("--roofline-reps", type=int, default=5)
+    ap.add_argument("--fiducials", default="", help="BASELINE.json configs[4]-style run: GXxGY planar grid of square fiducials per frame, e.g. 6x4")
     ap.add_argument("--fisheye", action="store_true", help="BASELINE.json configs[3]-style run: fisheye model (use with --width 3840 --height 2160 --batch 256)")
     return ap.parse_args()
 
@@ -64,6 +65,11 @@ def main():
     abi.set_geometry(cfg, a.width, a.height, abi.RCC_PIX_BGR8)
     if a.fisheye:
         abi.set_distortion(cfg, abi.RCC_DIST_FISHEYE, abi.FISHEYE_DEFAULT)
+    fid = None
+    if a.fiducials:
+        fid = tuple(int(v) for v in a.fiducials.lower().split("x"))
+        family = abi.load_family()
+        abi.set_fiducial_target(cfg, family, tag_size=0.10, max_targets=fid[0] * fid[1])
     cfg.device = local
     cfg.batch_capacity = a.batch
     det = api.Detector(cfg)
@@ -76,7 +82,12 @@ def main():
     sp = abi.default_synth_params()
     first = rank * B
     frames = torch.empty((B, cfg.frame_bytes), dtype=torch.uint8, device=dev)
-    poses = synth.sample_poses(B, cfg, first_index=first)
+    if fid:
+        (fhx, fhy), _, _ = synth.fiducial_grid_layout(fid[0], fid[1], cfg.tag_size)
+        sp.fid_grid_x, sp.fid_grid_y, sp.fid_gap_permille = fid[0], fid[1], 500
+        poses = synth.sample_poses(B, cfg, first_index=first, z_range=(1.0, 2.0), max_tilt_deg=40, half_extent_m=(fhx, fhy))
+    else:
+        poses = synth.sample_poses(B, cfg, first_index=first)
 
     chunk = 64
     for s0 in range(0, B, chunk):
@@ -84,7 +95,7 @@ def main():
         det.synth_render(sp, poses[s0:s0 + n], frames[s0:s0 + n], first_index=first + s0)
     torch.cuda.synchronize()
 
-    gather = rdist.PoseGather(B, dev, world, dist)
+    gather = rdist.PoseGather(B * (fid[0] * fid[1] if fid else 1), dev, world, dist)
 
     def step():
         dets, _ = det.detect(frames, B, want_corners=False)
@@ -119,9 +130,10 @@ def main():
             "dtype": "u8/i32 pixel stages, f64 sub-pixel + PnP", "data": "synthetic",
             "config": {"workload": "batch of %d synthetic %dx%d BGR8 checkerboard frames per GPU, device-resident "
                                    "(BASELINE.json configs[1]); corners + PnP" % (B, a.width, a.height),
-                       "frames_per_step_per_gpu": B, "board": "8x6 inner corners, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
+                       "frames_per_step_per_gpu": B,
+                       "target": ("%dx%d square fiducials of 0.10 m per frame (build family36b), 4-point PnP per tag" % fid) if fid else "8x6 inner-corner checkerboard, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
                        "parallelism": "frame-sharded, 1 process per GPU, 1 all_gather of pose records per step"},
-            "boards_found_in_last_step": int(found), "stage_ms_last_step": timings,
+            "targets_found_in_last_step": int(found), "targets_expected_per_step": int(world * B * (fid[0] * fid[1] if fid else 1)), "stage_ms_last_step": timings,
         }
 
     # ---- roofline of the threshold+corner pass (the kernel BASELINE.json's north_star names) and
@@ -156,7 +168,7 @@ def main():
 
     # ---- CPU baseline (the oracle = "port"; the reference's OpenCV path cannot be built here) and
     # accuracy against it, on a bounded sample, rank 0 at N=1 only
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not fid:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import orc_py
         S = min(a.cpu_sample, B)

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
   __shared__ int8_t s_dx[FID_MAXN], s_dy[FID_MAXN];
   __shared__ uint8_t s_ok[FID_MAXN], s_thr[FID_MAXN], s_hitf[FID_MAXN];
   __shared__ fid_hit s_hit[FID_MAXN];
-  __shared__ int s_count;
+  __shared__ int16_t s_cidx[FID_MAXN];     // indices of the convex black corners, ascending
+  __shared__ int s_nc;
   const int f = blockIdx.x, tid = threadIdx.x;
   rcc_frame_corners* out = fc + f;
   if (out->status != 0) { if (tid == 0) ndet[f] = 0; return; }
@@ -206,24 +207,42 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
     s_hitf[i] = 0;
   }
   __syncthreads();
+  // ordered compaction of the classified corners: only they can be linked (typically a third of n),
+  // and ascending order keeps the specification's tie-break (nearest, then smallest index)
+  if (tid < 64) {
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int i = c0 + tid;
+      const bool k = (i < n) && s_ok[i];
+      const unsigned long long bal = __ballot(k);
+      if (k) s_cidx[base + __popcll(bal & ((1ull << tid) - 1ull))] = (int16_t)i;
+      base += __popcll(bal);
+    }
+    if (tid == 0) s_nc = base;
+  }
+  __syncthreads();
+  const int nc = s_nc;
   // phase 2: link along d1 (black on the (-dy, dx) side of the direction of travel): nearest accepted
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += 256) s_nxt[i] = -1;
+  __syncthreads();
+  for (int ci = tid; ci < nc; ci += 256) {
+    const int i = s_cidx[ci];
     int best = -1;
-    if (s_ok[i]) {
-      const long long dx = s_dx[i], dy = s_dy[i], dd = dx * dx + dy * dy;
-      const int xi = s_px[i], yi = s_py[i], t = s_thr[i];
-      long long bestd = 0;
-      for (int j = 0; j < n; ++j) {
-        if (j == i || !s_ok[j]) continue;
-        const long long wx = s_px[j] - xi, wy = s_py[j] - yi, ww = wx * wx + wy * wy;
-        if (ww < 64) continue;
-        if (wx * dx + wy * dy <= 0) continue;
-        const long long cr = wx * dy - wy * dx;
-        if (8 * cr * cr > ww * dd) continue;
-        if (best >= 0 && ww >= bestd) continue;
-        if (!fid_edge_ok(g, w, h, xi, yi, (int)wx, (int)wy, (int)-dy, (int)dx, t)) continue;
-        best = j; bestd = ww;
-      }
+    const int dx = s_dx[i], dy = s_dy[i], dd = dx * dx + dy * dy;
+    const int xi = s_px[i], yi = s_py[i], t = s_thr[i];
+    int bestd = 0;
+    for (int cj = 0; cj < nc; ++cj) {
+      const int j = s_cidx[cj];
+      if (j == i) continue;
+      const int wx = s_px[j] - xi, wy = s_py[j] - yi;
+      const int ww = wx * wx + wy * wy;                    // <= 2 * 16384^2 fits int32
+      if (ww < 64) continue;
+      if (wx * dx + wy * dy <= 0) continue;
+      const long long cr = (long long)wx * dy - (long long)wy * dx;
+      if (8 * cr * cr > (long long)ww * dd) continue;
+      if (best >= 0 && ww >= bestd) continue;
+      if (!fid_edge_ok(g, w, h, xi, yi, wx, wy, -dy, dx, t)) continue;
+      best = j; bestd = ww;
     }
     s_nxt[i] = (int16_t)best;
   }

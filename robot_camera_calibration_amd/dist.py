@@ -28,6 +28,15 @@ def pack(dets, nslots, frame_offset=0):
     if len(dets) == 0:
         return a
     d = np.asarray(dets)
+    if len(d) > nslots or len(np.unique(d["frame"])) != len(d):
+        # several targets per frame (fiducials): slot = running index, capped at nslots
+        d = d[:nslots]
+        fr = np.arange(len(d))
+        a[fr, 0] = 1.0
+        a[fr, 1] = d["frame"] + frame_offset
+        a[fr, 2] = d["id"]; a[fr, 3] = d["ncorners"]; a[fr, 4:7] = d["rvec"]; a[fr, 7:10] = d["tvec"]; a[fr, 10] = d["rms"]
+        a[fr, 11:17] = d["corners"].reshape(len(d), 8)[:, :6]
+        return a
     fr = d["frame"]
     a[fr, 0] = 1.0
     a[fr, 1] = fr + frame_offset
