@@ -210,6 +210,9 @@ int rcc_stage_threshold_corner(rcc_handle* h, const void* d_grey, int32_t nframe
  * (needs width % 64 == 0); -1 = automatic.  Returns the previous value. */
 int rcc_set_dense_variant(rcc_handle* h, int variant);
 int rcc_set_ingest_variant(rcc_handle* h, int variant);
+/* fast dense variant only: 1 (default) lets it skip the corner stages on wave-rows whose tiles are all
+ * low-contrast (exact: see k_dense_fast.hip), 0 disables the skip.  Returns the previous value. */
+int rcc_set_dense_skip(rcc_handle* h, int on);
 /* PnP mapping: 0 = one lane per target, 1 = one wavefront per target when a target has more than
  * 8 points, -1 = automatic (same as 1). */
 int rcc_set_pnp_variant(rcc_handle* h, int variant);

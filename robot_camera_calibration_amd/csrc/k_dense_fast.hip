@@ -43,7 +43,7 @@ struct LRow { int r0, r2, rL, rR; };                   // lattice row of respons
 
 __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__ grey, int w, int h,
                                                      int nstrips, int nseg, int seg_tiles, int nframes,
-                                                     int min_contrast, int hthresh, int margin, int cap,
+                                                     int min_contrast, int hthresh, int margin, int cap, int allow_skip,
                                                      uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand,
                                                      int32_t* __restrict__ cand_count)
 {
@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
   };
 
   // one image row: G = its grey dword; (a, b) = Sobel partials of rows r-2, r-1; n receives row r's.
+  // rmask != 0: the lane's tile at the lattice row being produced is flat => its response cannot
+  // reach hthresh (host-checked bound), so it is replaced by INT32_MIN
   auto do_row = [&](const int r, const int k, const unsigned G, const SobelRow& a, const SobelRow& b, SobelRow& n,
-                    u16x2& tmn, u16x2& tmx) {
+                    const int rmask) {
     // ---- stage A (row r): horizontal Sobel partials, natural-order pixel pairs
     const unsigned GL = (unsigned)from_left((int)G, (int)G), GR = (unsigned)from_right((int)G, (int)G);
     const u16x2 n0 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));    // [p0,p1]
@@ -91,8 +93,6 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
     const u16x2 mm = as_u(__builtin_amdgcn_perm(0u, G, 0x0C020C01u));    // [p1,p2]
     const u16x2 lh = as_u(__builtin_amdgcn_perm(GL, G, 0x0C000C07u));    // [p-1,p0]
     const u16x2 rh = as_u(__builtin_amdgcn_perm(GR, G, 0x0C040C03u));    // [p3,p4]
-    tmn = __builtin_elementwise_min(tmn, __builtin_elementwise_min(n0, n1));
-    tmx = __builtin_elementwise_max(tmx, __builtin_elementwise_max(n0, n1));
     const i16x2 two = (i16x2)(2);
     n.dh01 = as_i(bits(mm)) - as_i(bits(lh));                            // I[x+1]-I[x-1] for x = p0,p1
     n.dh23 = as_i(bits(rh)) - as_i(bits(mm));
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
       const int A2 = (qa.xx2 + qb.xx2 + hc.xx2) >> 4, B2 = (qa.xy2 + qb.xy2 + hc.xy2) >> 4, C2 = (qa.yy2 + qb.yy2 + hc.yy2) >> 4;
       const unsigned tr0 = (unsigned)(A0 + C0), tr2 = (unsigned)(A2 + C2);
       LRow Rn;
-      Rn.r0 = __mul24(A0, C0) - __mul24(B0, B0) - (int)(__umul24(tr0, tr0) >> 4);
-      Rn.r2 = __mul24(A2, C2) - __mul24(B2, B2) - (int)(__umul24(tr2, tr2) >> 4);
+      Rn.r0 = rmask ? INT32_MIN : __mul24(A0, C0) - __mul24(B0, B0) - (int)(__umul24(tr0, tr0) >> 4);
+      Rn.r2 = rmask ? INT32_MIN : __mul24(A2, C2) - __mul24(B2, B2) - (int)(__umul24(tr2, tr2) >> 4);
       Rn.rL = from_left(Rn.r2, INT32_MIN);
       Rn.rR = from_right(Rn.r0, INT32_MIN);
       hprev = hc;
@@ -170,54 +170,99 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
     }
   };
 
-  // one tile row t: P / C / N = grey of tile rows t-1 / t / t+1 (N is loaded here), ha / hb = tile
-  // statistics of rows t-2 / t-1, hn receives row t's; (sa, sb, sc) = Sobel sets in role order
-  auto do_tile = [&](const int t, const Tile4& P, const Tile4& C, Tile4& N, const TStat& ha, const TStat& hb, TStat& hn,
-                     SobelRow& sa, SobelRow& sb, SobelRow& sc) {
-    N.g0 = load_row(4 * t + 4); N.g1 = load_row(4 * t + 5); N.g2 = load_row(4 * t + 6); N.g3 = load_row(4 * t + 7);
+  // One iteration t runs two coupled pipelines:
+  //   FRONT (tile row t): statistics of its 4 rows (C), horizontal + vertical dilation => threshold
+  //     level and flatness flag of tile row t-1.  N2 prefetches tile row t+2 (two iterations ahead:
+  //     with the back stage skipped an iteration is too short to cover HBM latency otherwise).
+  //   BACK (tile row tau = t-2): threshold OUTPUT of tau and the Sobel / structure-tensor / response /
+  //     selection stages.  A tile whose dilated contrast is below min_contrast cannot hold a candidate
+  //     (its 7x7 supports lie in the flat 12x12 neighbourhood, so R <= ((25*gmax^2)>>4)^2 < hthresh --
+  //     checked on the host, else allow_skip = 0), and a candidate's comparison against such a
+  //     neighbour is decided by hthresh alone.  So when every lane's tile is flat in tile rows tau-1,
+  //     tau, tau+1 the corner stages are skipped for tau (and its threshold output is the constant
+  //     127, no pixels needed); responses inside flat tiles are masked to INT32_MIN.  Outputs are
+  //     unchanged.  The four rows of tau are re-read (L2 hits: the front read them two iterations
+  //     ago), one iteration early (Bn -> Bc) so that their latency is covered too.
+  //   Fa / Fb / Fn = flatness of tile rows t-3 / t-2 / t-1 (Fn is set here); thrB / flatB = threshold
+  //   level and true flatness of tile row t-2 (carried from the previous iteration).
+  int thrB = 0, flatB = 1;
+  Tile4 Bc = { 0, 0, 0, 0 }, Bn = Bc;
+  auto do_tile = [&](const int t, const Tile4& C, Tile4& N2, const TStat& ha, const TStat& hb, TStat& hn,
+                     const int Fa, const int Fb, int& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
+    N2.g0 = load_row(4 * t + 8); N2.g1 = load_row(4 * t + 9); N2.g2 = load_row(4 * t + 10); N2.g3 = load_row(4 * t + 11);
+    Bn.g0 = load_row(4 * t - 4); Bn.g1 = load_row(4 * t - 3); Bn.g2 = load_row(4 * t - 2); Bn.g3 = load_row(4 * t - 1);   // rows of tau+1
+    // ---- FRONT
     u16x2 tmn = (u16x2)(255), tmx = (u16x2)(0);
-    do_row(4 * t + 0, 0, C.g0, sa, sb, sc, tmn, tmx);
-    do_row(4 * t + 1, 1, C.g1, sb, sc, sa, tmn, tmx);
-    do_row(4 * t + 2, 2, C.g2, sc, sa, sb, tmn, tmx);
-    do_row(4 * t + 3, 3, C.g3, sa, sb, sc, tmn, tmx);
-    // ---- stage G: threshold.  Statistics of tile row t, then output of tile row t-1.
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned G = (k == 0) ? C.g0 : (k == 1) ? C.g1 : (k == 2) ? C.g2 : C.g3;
+      const u16x2 n0 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));
+      const u16x2 n1 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C030C02u));
+      tmn = __builtin_elementwise_min(tmn, __builtin_elementwise_min(n0, n1));
+      tmx = __builtin_elementwise_max(tmx, __builtin_elementwise_max(n0, n1));
+    }
     const int tmin = min((int)tmn.x, (int)tmn.y), tmax = max((int)tmx.x, (int)tmx.y);
     hn.hmin = min(tmin, min(from_left(tmin, tmin), from_right(tmin, tmin)));
     hn.hmax = max(tmax, max(from_left(tmax, tmax), from_right(tmax, tmax)));
     const int dmin = min(ha.hmin, min(hb.hmin, hn.hmin)), dmax = max(ha.hmax, max(hb.hmax, hn.hmax));
     const int range = dmax - dmin;
-    const int thr = dmin + (range >> 1);
-    const bool flat = range < min_contrast;
-    const int tt = t - 1;
-    if (tt >= t0 && tt < t1 && lane_out) {
-      // per byte: v > thr  <=>  v >= thr+1 (thr <= 254 whenever the tile is not flat).  SWAR unsigned
-      // byte compare: d = (x|H) - (y&~H) has its per-byte MSB set iff the low 7 bits of x >= those of y
-      // (no borrow crosses bytes); where the MSBs of x and y differ x's decides, else d's.
-      const unsigned H = 0x80808080u;
-      const unsigned y4 = (unsigned)(thr + 1) * 0x01010101u;
-      const unsigned ylo = y4 & ~H, ny = ~y4;
+    const int thrN = dmin + (range >> 1);
+    const int flatN = range < min_contrast;
+    // the flag is trusted only where the three tile rows it rests on were really read (t-1 >= t0);
+    // warm-up rows count as non-flat (conservative: the back stage runs there as before)
+    Fn = (flatN && allow_skip && (t - 1) >= t0) ? 1 : 0;
+    // ---- BACK
+    const int tau = t - 2;
+    if (tau >= t0 - 2) {
+      const bool out_row = (tau >= t0) && (tau < t1) && lane_out;
+      if (__any(!(Fa && Fb && Fn))) {
+        if (out_row) {
+          // per byte: v > thr <=> v >= thr+1 (thr <= 254 whenever the tile is not flat).  SWAR unsigned byte
+          // compare: d = (x|H) - (y&~H) has its per-byte MSB set iff the low 7 bits of x >= those of y (no
+          // borrow crosses bytes); where the MSBs of x and y differ x's decides, else d's.
+          const unsigned H = 0x80808080u;
+          const unsigned y4 = (unsigned)(thrB + 1) * 0x01010101u;
+          const unsigned ylo = y4 & ~H, ny = ~y4;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const unsigned x = (k == 0) ? P.g0 : (k == 1) ? P.g1 : (k == 2) ? P.g2 : P.g3;
-        const unsigned d = (x | H) - ylo;
-        const unsigned xy = x ^ y4;
-        const unsigned ge = (((x & ny) & xy) | (d & ~xy)) & H;      // bitfield select on xy
-        unsigned o = (ge >> 7) * 255u;                               // 0x01 -> 0xFF per byte, no carries
-        if (flat) o = 0x7F7F7F7Fu;
-        *reinterpret_cast<unsigned*>(bo + (size_t)(4 * tt + k) * w + x0) = o;
+          for (int k = 0; k < 4; ++k) {
+            const unsigned x = (k == 0) ? Bc.g0 : (k == 1) ? Bc.g1 : (k == 2) ? Bc.g2 : Bc.g3;
+            const unsigned d = (x | H) - ylo;
+            const unsigned xy = x ^ y4;
+            const unsigned ge = (((x & ny) & xy) | (d & ~xy)) & H;      // bitfield select on xy
+            unsigned o = (ge >> 7) * 255u;                               // 0x01 -> 0xFF per byte, no carries
+            if (flatB) o = 0x7F7F7F7Fu;
+            *reinterpret_cast<unsigned*>(bo + (size_t)(4 * tau + k) * w + x0) = o;
+          }
+        }
+        do_row(4 * tau + 0, 0, Bc.g0, sa, sb, sc, 0);
+        do_row(4 * tau + 1, 1, Bc.g1, sb, sc, sa, Fa);     // produces lattice row 4*tau-2, in tile row tau-1
+        do_row(4 * tau + 2, 2, Bc.g2, sc, sa, sb, 0);
+        do_row(4 * tau + 3, 3, Bc.g3, sa, sb, sc, Fb);     // produces lattice row 4*tau, in tile row tau
+      } else {
+        if (out_row) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) *reinterpret_cast<unsigned*>(bo + (size_t)(4 * tau + k) * w + x0) = 0x7F7F7F7Fu;
+        }
+        Ra.r0 = Ra.r2 = Ra.rL = Ra.rR = INT32_MIN;        // the two lattice rows not produced lie in flat tiles
+        Rb = Ra;
       }
     }
+    thrB = thrN; flatB = flatN;
+    Bc = Bn;
   };
 
   int t = t0 - 2;
-  T1.g0 = load_row(4 * t); T1.g1 = load_row(4 * t + 1); T1.g2 = load_row(4 * t + 2); T1.g3 = load_row(4 * t + 3);
+  T0.g0 = load_row(4 * t); T0.g1 = load_row(4 * t + 1); T0.g2 = load_row(4 * t + 2); T0.g3 = load_row(4 * t + 3);
+  T1.g0 = load_row(4 * t + 4); T1.g1 = load_row(4 * t + 5); T1.g2 = load_row(4 * t + 6); T1.g3 = load_row(4 * t + 7);
+  int F0 = 0, F1 = 0, F2 = 0;
+  const int tend = t1 + 2;                                // the back stage lags the front by two tile rows
   for (;;) {
-    do_tile(t, T0, T1, T2, H0, H1, H2, S0, S1, S2);
-    if (++t > t1) break;
-    do_tile(t, T1, T2, T0, H1, H2, H0, S1, S2, S0);
-    if (++t > t1) break;
-    do_tile(t, T2, T0, T1, H2, H0, H1, S2, S0, S1);
-    if (++t > t1) break;
+    do_tile(t, T0, T2, H0, H1, H2, F0, F1, F2, S0, S1, S2);
+    if (++t > tend) break;
+    do_tile(t, T1, T0, H1, H2, H0, F1, F2, F0, S1, S2, S0);
+    if (++t > tend) break;
+    do_tile(t, T2, T1, H2, H0, H1, F2, F0, F1, S2, S0, S1);
+    if (++t > tend) break;
   }
 }
 
@@ -239,10 +284,14 @@ hipError_t rcc_launch_dense_fast(rcc_handle* h, const uint8_t* d_grey, int nfram
   const long long want = 256LL * 4 * 8;
   while (seg_tiles > 8 && (long long)nstrips * nframes * ((th + seg_tiles - 1) / seg_tiles) < want) seg_tiles = (seg_tiles + 1) / 2;
   const int nseg = (th + seg_tiles - 1) / seg_tiles;
+  // flat-tile skip is exact only if a response inside a flat 12x12 neighbourhood stays below the threshold
+  const int cdiff = c.thr_min_contrast - 1;
+  const long long gmax = cdiff > 0 ? ((4LL * cdiff + 7) >> 3) : 0, amax = (25 * gmax * gmax) >> 4;
+  const int allow_skip = (h->dense_skip != 0) && (cdiff >= 0) && (amax * amax < (long long)c.harris_thresh) ? 1 : 0;
   const long long njobs = (long long)nstrips * nseg * nframes;
   const int blocks = (int)((njobs + 3) / 4);
   hipLaunchKernelGGL(k_dense_march, dim3(blocks), dim3(256), 0, s, d_grey, w, ht, nstrips, nseg, seg_tiles, nframes,
-                     c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, d_bin, d_cand, d_cand_count);
+                     c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
   return hipGetLastError();
 }
 

@@ -140,6 +140,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->undist = cfg->undistort && cfg->dist_model != RCC_DIST_NONE;
   h->dense_variant = -1;
   h->ingest_variant = -1;
+  h->dense_skip = 1;
   h->pnp_variant = -1;
   h->kept_cap = (cfg->target_kind == RCC_TARGET_FIDUCIAL) ? RCC_MAX_KEPT_FIDUCIAL : RCC_MAX_KEPT;
   h->pnp_solver = 1;
@@ -209,6 +210,13 @@ int rcc_set_dense_variant(rcc_handle* h, int variant)
   if (!h) return RCC_ERR_ARG;
   int p = h->dense_variant;
   h->dense_variant = variant;
+  return p;
+}
+int rcc_set_dense_skip(rcc_handle* h, int on)
+{
+  if (!h) return RCC_ERR_ARG;
+  int p = h->dense_skip;
+  h->dense_skip = on ? 1 : 0;
   return p;
 }
 int rcc_set_pnp_variant(rcc_handle* h, int variant)

@@ -58,6 +58,7 @@ struct rcc_handle {
   hipEvent_t ev[8];
   float last_ms[5];
   int dense_variant, ingest_variant;
+  int dense_skip;           // 1: the fast dense kernel may skip flat wave-rows (exact); 0: never (A/B, tests)
   int pnp_variant;          // -1 auto, 0 lane per target, 1 wavefront per target (board)
   int pnp_solver;           // 0 eigen, 1 Cholesky (default)
   int kept_cap;             // stride of the per-frame suppressed-list buffers: 256 (board) or 2048 (fiducials)

@@ -256,9 +256,10 @@ def test_kernel_variants_bit_identical(torch_cuda, oracle, pixfmt):
     px = cfg.width * cfg.height
     outs = {}
     for iv in (0, 1):
-        for dv in (0, 1):
+        for dv in (0, 1, 2):      # 2 = fast kernel with the flat-row skip disabled
             det.set_ingest_variant(iv)
-            det.set_dense_variant(dv)
+            det.set_dense_variant(min(dv, 1))
+            det.set_dense_skip(0 if dv == 2 else 1)
             grey = torch.zeros((n, px), dtype=torch.uint8, device="cuda:0")
             binm = torch.zeros((n, px), dtype=torch.uint8, device="cuda:0")
             cand = torch.zeros((n, cfg.max_candidates * 8), dtype=torch.uint8, device="cuda:0")
