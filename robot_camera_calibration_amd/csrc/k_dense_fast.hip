@@ -41,12 +41,14 @@ struct LRow { int r0, r2, rL, rR; };                   // lattice row of respons
 #define STRIP_USE 244   // useful pixels per wave strip: lanes 2..62 (the left lattice neighbour of the
                         // first useful pixel needs a 5-pixel halo => two halo lanes on the left, one on the right)
 
+template <int MODE>   // 0: the pass; 1: its loads and stores only (experiment: what the access pattern alone costs)
 __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__ grey, int w, int h,
                                                      int nstrips, int nseg, int seg_tiles, int nframes,
-                                                     int min_contrast, int hthresh, int margin, int cap, int allow_skip,
+                                                     int min_contrast, int hthresh, int margin, int cap, int allow_skip_exp,
                                                      uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand,
                                                      int32_t* __restrict__ cand_count)
 {
+  const int allow_skip = allow_skip_exp & 1, exp_al = allow_skip_exp & 2, exp_ns = allow_skip_exp & 4;   // EXPERIMENT bits
   const int lane = threadIdx.x & 63;
   // the job index is wave-uniform: tell the compiler, so strip/segment/frame/row arithmetic is scalar
   const int job = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -76,10 +78,24 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
   HSum hprev = { 0, 0, 0, 0, 0, 0 }, qa = hprev, qb = hprev;     // qa: pair closed at k=0, qb: pair closed at k=2
   LRow Ra = { INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN }, Rb = Ra;   // lattice rows y-4, y-2
 
+  // addressing: buffer descriptors of the frame's grey / binary image + per-lane byte offset (VGPR, constant)
+  // + row offset (SGPR): no vector arithmetic per access (a per-lane 64-bit multiply-add per access would cost
+  // more than the whole threshold stage).  Out-of-range never happens (rows clamped, columns clamped).
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(gf), 0, w * h, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(bo, 0, w * h, 0x00020000);
+  const int xlu = xl, xou = exp_al ? strip * 256 + 4 * lane : max(x0, 0);
   auto load_row = [&](int r) -> unsigned {
-    int rr = min(max(r, 0), h - 1);                     // scalar
-    return *reinterpret_cast<const unsigned*>(gf + (size_t)rr * w + xl);
+    const int rr = min(max(r, 0), h - 1);               // scalar
+    return __builtin_amdgcn_raw_buffer_load_b32(rs_g, xlu, rr * w, 0);
   };
+  auto store_row = [&](int r, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, rs_b, xou, r * w, 0); };
+  // "don't care" values that cost no instruction (the compiler may leave anything in the register)
+  auto dontcare = [](int& v) { asm volatile("" : "=v"(v)); };
+  auto dontcare_s = [&](SobelRow& q) {
+    int a, b, c, d; dontcare(a); dontcare(b); dontcare(c); dontcare(d);
+    q.dh01 = __builtin_bit_cast(i16x2, a); q.dh23 = __builtin_bit_cast(i16x2, b); q.sh01 = __builtin_bit_cast(i16x2, c); q.sh23 = __builtin_bit_cast(i16x2, d);
+  };
+  auto dontcare_h = [&](HSum& q) { dontcare(q.xx0); dontcare(q.xy0); dontcare(q.yy0); dontcare(q.xx2); dontcare(q.xy2); dontcare(q.yy2); };
 
   // one image row: G = its grey dword; (a, b) = Sobel partials of rows r-2, r-1; n receives row r's.
   // rmask != 0: the lane's tile at the lattice row being produced is flat => its response cannot
@@ -191,6 +207,17 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
                      const int Fa, const int Fb, int& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
     N2.g0 = load_row(4 * t + 8); N2.g1 = load_row(4 * t + 9); N2.g2 = load_row(4 * t + 10); N2.g3 = load_row(4 * t + 11);
     Bn.g0 = load_row(4 * t - 4); Bn.g1 = load_row(4 * t - 3); Bn.g2 = load_row(4 * t - 2); Bn.g3 = load_row(4 * t - 1);   // rows of tau+1
+    if (MODE == 1) {
+      const int tau = t - 2;
+      if ((tau >= t0) && (tau < t1) && lane_out) {
+        store_row(4 * tau + 0, Bc.g0 ^ C.g0);
+        store_row(4 * tau + 1, Bc.g1 ^ C.g1);
+        store_row(4 * tau + 2, Bc.g2 ^ C.g2);
+        store_row(4 * tau + 3, Bc.g3 ^ C.g3);
+      }
+      Bc = Bn;
+      return;
+    }
     // ---- FRONT
     u16x2 tmn = (u16x2)(255), tmx = (u16x2)(0);
 #pragma unroll
@@ -208,20 +235,21 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
     const int range = dmax - dmin;
     const int thrN = dmin + (range >> 1);
     const int flatN = range < min_contrast;
-    // the flag is trusted only where the three tile rows it rests on were really read (t-1 >= t0);
-    // warm-up rows count as non-flat (conservative: the back stage runs there as before)
-    Fn = (flatN && allow_skip && (t - 1) >= t0) ? 1 : 0;
+    // warm-up: tile rows below t0-1 produce no lattice row this job needs (the first needed one is
+    // 4*t0-2, in tile row t0-1, whose statistics rest on t0-2..t0, all read), so their flag is "don't
+    // care" = 1: back(t0-2) then runs iff tile row t0-1 is not flat, back(t0-1) iff t0-1 or t0 is not.
+    Fn = allow_skip ? (((t - 1) < t0 - 1) ? 1 : flatN) : 0;
     // ---- BACK
     const int tau = t - 2;
     if (tau >= t0 - 2) {
-      const bool out_row = (tau >= t0) && (tau < t1) && lane_out;
+      const bool out_row = (tau >= t0) && (tau < t1) && (exp_al ? (strip * 256 + 4 * lane < w) : lane_out) && !exp_ns;
       if (__any(!(Fa && Fb && Fn))) {
         if (out_row) {
           // per byte: v > thr <=> v >= thr+1 (thr <= 254 whenever the tile is not flat).  SWAR unsigned byte
           // compare: d = (x|H) - (y&~H) has its per-byte MSB set iff the low 7 bits of x >= those of y (no
           // borrow crosses bytes); where the MSBs of x and y differ x's decides, else d's.
           const unsigned H = 0x80808080u;
-          const unsigned y4 = (unsigned)(thrB + 1) * 0x01010101u;
+          const unsigned y4 = __builtin_amdgcn_perm(0u, (unsigned)(thrB + 1), 0u);   // byte 0 replicated
           const unsigned ylo = y4 & ~H, ny = ~y4;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -229,9 +257,9 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
             const unsigned d = (x | H) - ylo;
             const unsigned xy = x ^ y4;
             const unsigned ge = (((x & ny) & xy) | (d & ~xy)) & H;      // bitfield select on xy
-            unsigned o = (ge >> 7) * 255u;                               // 0x01 -> 0xFF per byte, no carries
+            unsigned o = ge | (ge - (ge >> 7));                          // 0x80 -> 0xFF per byte, no carries
             if (flatB) o = 0x7F7F7F7Fu;
-            *reinterpret_cast<unsigned*>(bo + (size_t)(4 * tau + k) * w + x0) = o;
+            store_row(4 * tau + k, o);
           }
         }
         do_row(4 * tau + 0, 0, Bc.g0, sa, sb, sc, 0);
@@ -241,10 +269,14 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
       } else {
         if (out_row) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) *reinterpret_cast<unsigned*>(bo + (size_t)(4 * tau + k) * w + x0) = 0x7F7F7F7Fu;
+          for (int k = 0; k < 4; ++k) store_row(4 * tau + k, 0x7F7F7F7Fu);
         }
         Ra.r0 = Ra.r2 = Ra.rL = Ra.rR = INT32_MIN;        // the two lattice rows not produced lie in flat tiles
         Rb = Ra;
+        // the Sobel partials and row sums now describe rows that were not read; everything they can still
+        // reach is a masked response (see above), so their contents do not matter: no copies at the join
+        dontcare_s(sa); dontcare_s(sb); dontcare_s(sc);
+        dontcare_h(hprev); dontcare_h(qa); dontcare_h(qb);
       }
     }
     thrB = thrN; flatB = flatN;
@@ -254,7 +286,7 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
   int t = t0 - 2;
   T0.g0 = load_row(4 * t); T0.g1 = load_row(4 * t + 1); T0.g2 = load_row(4 * t + 2); T0.g3 = load_row(4 * t + 3);
   T1.g0 = load_row(4 * t + 4); T1.g1 = load_row(4 * t + 5); T1.g2 = load_row(4 * t + 6); T1.g3 = load_row(4 * t + 7);
-  int F0 = 0, F1 = 0, F2 = 0;
+  int F0 = allow_skip, F1 = allow_skip, F2 = allow_skip;
   const int tend = t1 + 2;                                // the back stage lags the front by two tile rows
   for (;;) {
     do_tile(t, T0, T2, H0, H1, H2, F0, F1, F2, S0, S1, S2);
@@ -281,16 +313,23 @@ hipError_t rcc_launch_dense_fast(rcc_handle* h, const uint8_t* d_grey, int nfram
   // segments: enough jobs to fill the chip (>= ~8 waves per SIMD in flight), but at least 8 tile
   // rows per segment so the 3 warm-up tile rows stay a small fraction
   int seg_tiles = th;
-  const long long want = 256LL * 4 * 8;
+  static const long long want_mul = getenv("RCC_DENSE_WANT") ? atoll(getenv("RCC_DENSE_WANT")) : 8;
+  const long long want = 256LL * 4 * want_mul;
   while (seg_tiles > 8 && (long long)nstrips * nframes * ((th + seg_tiles - 1) / seg_tiles) < want) seg_tiles = (seg_tiles + 1) / 2;
   const int nseg = (th + seg_tiles - 1) / seg_tiles;
   // flat-tile skip is exact only if a response inside a flat 12x12 neighbourhood stays below the threshold
   const int cdiff = c.thr_min_contrast - 1;
   const long long gmax = cdiff > 0 ? ((4LL * cdiff + 7) >> 3) : 0, amax = (25 * gmax * gmax) >> 4;
-  const int allow_skip = (h->dense_skip != 0) && (cdiff >= 0) && (amax * amax < (long long)c.harris_thresh) ? 1 : 0;
+  static const int expbits = getenv("RCC_DENSE_EXP") ? atoi(getenv("RCC_DENSE_EXP")) : 0;
+  const int allow_skip = ((h->dense_skip != 0) && (cdiff >= 0) && (amax * amax < (long long)c.harris_thresh) ? 1 : 0) | expbits;
   const long long njobs = (long long)nstrips * nseg * nframes;
   const int blocks = (int)((njobs + 3) / 4);
-  hipLaunchKernelGGL(k_dense_march, dim3(blocks), dim3(256), 0, s, d_grey, w, ht, nstrips, nseg, seg_tiles, nframes,
+  static const int memonly = getenv("RCC_DENSE_MEMONLY") ? atoi(getenv("RCC_DENSE_MEMONLY")) : 0;
+  if (memonly)
+    hipLaunchKernelGGL(k_dense_march<1>, dim3(blocks), dim3(256), 0, s, d_grey, w, ht, nstrips, nseg, seg_tiles, nframes,
+                       c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
+  else
+  hipLaunchKernelGGL(k_dense_march<0>, dim3(blocks), dim3(256), 0, s, d_grey, w, ht, nstrips, nseg, seg_tiles, nframes,
                      c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
   return hipGetLastError();
 }
