@@ -186,34 +186,53 @@ __global__ __launch_bounds__(256) void k_ingest_gather(const uint8_t* __restrict
 #define ST_ROWS 24            // LDS rows per buffer
 #define ST_MAXG ((ST_PITCH / 16) * ST_ROWS)
 
+// 16 BGR pixels (48 B in three 16-B registers) -> 16 grey bytes.  grey = (1868 B + 9617 G + 4899 R + 8192) >> 14
+// evaluated exactly with byte dot products: each weight w = 64*(w >> 6) + (w & 63), so
+//   S = (dot4(px, w >> 6) << 8) + dot4(px, 4*(w & 63)) + 32768 = 4 * (sum + 8192) < 2^24
+// and the grey value is byte 2 of S (bits 23:16 = (sum + 8192) >> 14).  17 instructions per 4 pixels.
+__device__ __forceinline__ uint32_t rcc_grey4(uint32_t d0, uint32_t d1, uint32_t d2)
+{
+  // bytes: d0 = B0 G0 R0 B1, d1 = G1 R1 B2 G2, d2 = R2 B3 G3 R3
+  const uint32_t WHI = 29u | (150u << 8) | (76u << 16);            // w >> 6 for B, G, R
+  const uint32_t WLO = 48u | (68u << 8) | (140u << 16);            // 4 * (w & 63)
+  const uint32_t p1 = __builtin_amdgcn_alignbyte(d1, d0, 3);       // B1 G1 R1 .
+  const uint32_t p2 = __builtin_amdgcn_alignbyte(d2, d1, 2);       // B2 G2 R2 .
+  const uint32_t s0 = (__builtin_amdgcn_udot4(d0, WHI, 0u, false) << 8) + __builtin_amdgcn_udot4(d0, WLO, 32768u, false);
+  const uint32_t s1 = (__builtin_amdgcn_udot4(p1, WHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p1, WLO, 32768u, false);
+  const uint32_t s2 = (__builtin_amdgcn_udot4(p2, WHI, 0u, false) << 8) + __builtin_amdgcn_udot4(p2, WLO, 32768u, false);
+  const uint32_t s3 = (__builtin_amdgcn_udot4(d2, WHI << 8, 0u, false) << 8) + __builtin_amdgcn_udot4(d2, WLO << 8, 32768u, false);
+  const uint32_t lo = __builtin_amdgcn_perm(s1, s0, 0x0C0C0602u);  // (s0.b2, s1.b2, 0, 0)
+  const uint32_t hi = __builtin_amdgcn_perm(s3, s2, 0x06020C0Cu);  // (0, 0, s2.b2, s3.b2)
+  return lo | hi;
+}
+
 __device__ __forceinline__ uint4 rcc_grey16(const uint4& a, const uint4& b, const uint4& d)
 {
-  const uint32_t in[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w };
-  uint32_t o[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    uint32_t d0 = in[3 * q], d1 = in[3 * q + 1], d2 = in[3 * q + 2];
-    int g0 = rcc_grey_of(d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255);
-    int g1 = rcc_grey_of(d0 >> 24, d1 & 255, (d1 >> 8) & 255);
-    int g2 = rcc_grey_of((d1 >> 16) & 255, d1 >> 24, d2 & 255);
-    int g3 = rcc_grey_of((d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24);
-    o[q] = (uint32_t)g0 | ((uint32_t)g1 << 8) | ((uint32_t)g2 << 16) | ((uint32_t)g3 << 24);
-  }
-  return make_uint4(o[0], o[1], o[2], o[3]);
+  return make_uint4(rcc_grey4(a.x, a.y, a.z), rcc_grey4(a.w, b.x, b.y), rcc_grey4(b.z, b.w, d.x), rcc_grey4(d.y, d.z, d.w));
 }
 
 template <int NCH>
 __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict__ frames,
                                                        int64_t frame_bytes, int stride, int w, int h,
                                                        rcc_cam cam, uint8_t* __restrict__ grey,
-                                                       int nframes, int fpb)
+                                                       int nframes, int fpb, int ntx, int ntiles, int per_xcd)
 {
+  // XCD-aware tile order.  Workgroups go round-robin to the 8 XCDs (id % 8), each with its own L2; the source
+  // boxes of neighbouring tiles overlap (about 14 source rows for 8 destination rows), so neighbours must share
+  // an L2 or the overlap is fetched again from the fabric (measured: 4.3x the algorithmic read bytes with the
+  // plain (x, y, z) grid).  XCD c walks, for each frame group, the contiguous raster range
+  // [c * per_xcd, (c + 1) * per_xcd) of tiles.
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int bz = kk / per_xcd;
+  const int tile = xcd * per_xcd + (kk - bz * per_xcd);
+  if (tile >= ntiles) return;                       // block-uniform
+  const int by = tile / ntx, bx = tile - by * ntx;
   __shared__ __attribute__((aligned(16))) uint8_t sbuf[2][ST_ROWS * ST_PITCH + 16];   // +16: dump slot of idle lanes
   __shared__ int s_red[4][4];
   const int tid = threadIdx.x;
   const int tx = tid & 31, ty = tid >> 5;           // 32 quads x 8 rows
-  const int x0 = blockIdx.x * ST_TW + tx * 4;
-  const int y = blockIdx.y * ST_TH + ty;
+  const int x0 = bx * ST_TW + tx * 4;
+  const int y = by * ST_TH + ty;
   const bool inside = (y < h) && (x0 < w);          // w % 16 == 0: a quad is all in or all out
   int32_t X[4], Y[4];
   int mnx = INT32_MAX, mxx = INT32_MIN, mny = INT32_MAX, mxy = INT32_MIN;
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   mxx = max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1]));
   mny = min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2]));
   mxy = max(max(s_red[0][3], s_red[1][3]), max(s_red[2][3], s_red[3][3]));
-  const int f0 = blockIdx.z * fpb;
+  const int f0 = bz * fpb;
   const int f1 = min(f0 + fpb, nframes);
   // box in source pixels: columns [bxa, bxa + 16*gw), rows [by0, by0 + bh); taps need +1
   const long long spanx = (long long)mxx - (long long)mnx, spany = (long long)mxy - (long long)mny;
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   const int gw = (spanx < 100000) ? (((mxx + 1) - bxa) / 16 + 1) : (1 << 20);
   const int bh = (spany < 100000) ? (mxy + 1 - mny + 1) : (1 << 20);
   const int by0 = mny;
-  const bool fits = (gw * 16 <= ST_PITCH) && (bh <= ST_ROWS) && (gw <= 64) && (bh <= 4 * (64 / (gw > 0 ? gw : 1)));   // block-uniform
+  const bool fits = (gw * 16 <= ST_PITCH) && (bh <= ST_ROWS) && (gw * bh <= 256);   // block-uniform
 
   if (!fits) {
     // gather path for this tile (same arithmetic, taps from global memory)
@@ -269,19 +288,28 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
 
   // one 16-pixel group per thread: wave v takes box rows v, v+4, ...; consecutive lanes take
   // consecutive groups of a row (coalesced 48 B per lane), so all four SIMDs share the load/convert work
-  const int wv = tid >> 6, ln = tid & 63;
-  const int grow = wv + 4 * (ln / gw), gcol = ln % gw;
+  // groups are dealt out linearly over the block's threads (the box has gw*bh <= 256 groups, typically ~140, so
+  // only the first waves convert); the starting wave rotates with the tile so that the four SIMDs of a CU share
+  // this work across the resident blocks
+  const int gidx = (tid + 64 * (tile & 3)) & 255;
+  const int grow = gidx / gw, gcol = gidx - grow * gw;
   const bool gact = grow < bh;
   const int gsx = bxa + 16 * gcol, gsy = by0 + grow;
   const bool gin = gact && gsx >= 0 && gsx < w && gsy >= 0 && gsy < h;
   const size_t goff = gin ? ((size_t)gsy * stride + (size_t)gsx * NCH) : 0;
   const int glds = grow * ST_PITCH + 16 * gcol;
-  // tap offsets inside the LDS box (bytes)
-  int toff[4], wts[4];
+  // per destination pixel: LDS dword address of the tap pair, byte shift, and the bilinear weights
+  // in the form the byte dot product takes them
+  int taddr[4], tsh[4], wx[4], wy0[4], wy1[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    toff[j] = ((Y[j] >> 5) - by0) * ST_PITCH + ((X[j] >> 5) - bxa);
-    wts[j] = ((X[j] & 31) << 8) | (Y[j] & 31);
+    const int toff = ((Y[j] >> 5) - by0) * ST_PITCH + ((X[j] >> 5) - bxa);
+    const int fx = X[j] & 31, fy = Y[j] & 31;
+    taddr[j] = toff & ~3;
+    tsh[j] = toff & 3;
+    wx[j] = (32 - fx) | (fx << 8);
+    wy0[j] = 64 * (32 - fy);
+    wy1[j] = 64 * fy;
   }
 
   // Straight-line frame loop (the variant requires width % 128 == 0 and height % 8 == 0, so every
@@ -290,7 +318,9 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   // group 0 -- so the compiler can count vmcnt instead of draining it.
   struct Regs { uint4 a, b, d; };
   const size_t goff_c = gin ? goff : ((size_t)min(max(gsy, 0), h - 1) * stride + (size_t)min(max(gsx, 0), w - 16) * NCH);
+  const bool wave_has = __any(gact);                 // wave-uniform: does this wave convert anything?
   auto issue = [&](int f, Regs& r) {
+    if (!wave_has) return;
     const int fc = min(f, f1 - 1);
     const uint4* p4 = reinterpret_cast<const uint4*>(frames + (size_t)fc * frame_bytes + goff_c);
     r.a = p4[0];
@@ -298,27 +328,30 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   };
   const int glds_c = gact ? glds : (ST_ROWS * ST_PITCH);          // idle lanes write a dump slot past the box
   auto commit = [&](uint8_t* buf, const Regs& r) {
+    if (!wave_has) return;
     uint4 gq = (NCH == 3) ? rcc_grey16(r.a, r.b, r.d) : r.a;
     if (!gin) gq = make_uint4(0, 0, 0, 0);
     *reinterpret_cast<uint4*>(buf + glds_c) = gq;
   };
   uint8_t* const out0 = grey + (size_t)y * w + x0;
   auto taps = [&](int f, const uint8_t* L) {
-    uint32_t out = 0;
+    uint32_t sv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int fx = wts[j] >> 8, fy = wts[j] & 31;
       // aligned dword pairs + v_alignbyte: a misaligned ds_read_u16 serialises in the LDS
       // (measured: ~48 LDS cycles per instruction, SQ_WAIT_INST_LDS = 51 % of wave time)
-      const uint32_t* t = reinterpret_cast<const uint32_t*>(L) + (toff[j] >> 2);
-      const uint32_t sh = (uint32_t)toff[j] & 3u;
-      const uint32_t top = __builtin_amdgcn_alignbyte(t[1], t[0], sh);
-      const uint32_t bot = __builtin_amdgcn_alignbyte(t[ST_PITCH / 4 + 1], t[ST_PITCH / 4], sh);
-      const int p00 = top & 255, p01 = (top >> 8) & 255, p10 = bot & 255, p11 = (bot >> 8) & 255;
-      int acc = (32 - fx) * (32 - fy) * p00 + fx * (32 - fy) * p01 + (32 - fx) * fy * p10 + fx * fy * p11;
-      out |= (uint32_t)((acc + 512) >> 10) << (8 * j);
+      const uint32_t* t = reinterpret_cast<const uint32_t*>(L + taddr[j]);
+      const uint32_t top = __builtin_amdgcn_alignbyte(t[1], t[0], (uint32_t)tsh[j]);                              // p00 p01 . .
+      const uint32_t bot = __builtin_amdgcn_alignbyte(t[ST_PITCH / 4 + 1], t[ST_PITCH / 4], (uint32_t)tsh[j]);    // p10 p11 . .
+      // acc = (32-fx)(32-fy) p00 + fx (32-fy) p01 + (32-fx) fy p10 + fx fy p11, rows first; 64*(acc+512) has
+      // (acc+512) >> 10 in byte 2
+      const uint32_t th = __builtin_amdgcn_udot4(top, (uint32_t)wx[j], 0u, false);
+      const uint32_t bh = __builtin_amdgcn_udot4(bot, (uint32_t)wx[j], 0u, false);
+      sv[j] = __umul24(th, (uint32_t)wy0[j]) + (__umul24(bh, (uint32_t)wy1[j]) + 32768u);
     }
-    *reinterpret_cast<uint32_t*>(out0 + (size_t)f * w * h) = out;
+    const uint32_t lo = __builtin_amdgcn_perm(sv[1], sv[0], 0x0C0C0602u);
+    const uint32_t hi = __builtin_amdgcn_perm(sv[3], sv[2], 0x06020C0Cu);
+    *reinterpret_cast<uint32_t*>(out0 + (size_t)f * w * h) = lo | hi;
   };
 
   // software pipeline, two frames of loads in flight: at step f the loads of f+2 are issued, the
@@ -364,18 +397,7 @@ __global__ __launch_bounds__(256) void k_grey_bgr_stream(const uint8_t* __restri
     if (aligned && c * 16 + 16 <= w) {
       const uint4* s4 = reinterpret_cast<const uint4*>(src);
       uint4 a = s4[0], b = s4[1], d = s4[2];
-      uint32_t in[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w };
-      uint32_t o[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {  // 4 pixels = 12 bytes = 3 dwords
-        uint32_t d0 = in[3 * q], d1 = in[3 * q + 1], d2 = in[3 * q + 2];
-        int g0 = rcc_grey_of(d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255);
-        int g1 = rcc_grey_of(d0 >> 24, d1 & 255, (d1 >> 8) & 255);
-        int g2 = rcc_grey_of((d1 >> 16) & 255, d1 >> 24, d2 & 255);
-        int g3 = rcc_grey_of((d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24);
-        o[q] = (uint32_t)g0 | ((uint32_t)g1 << 8) | ((uint32_t)g2 << 16) | ((uint32_t)g3 << 24);
-      }
-      *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<uint4*>(dst) = rcc_grey16(a, b, d);
     } else {
       int n = min(16, w - c * 16);
       for (int j = 0; j < n; ++j) dst[j] = (uint8_t)rcc_grey_of(src[3 * j], src[3 * j + 1], src[3 * j + 2]);
@@ -431,14 +453,16 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
                          ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0);
   if (variant < 0) variant = staged_ok ? 1 : 0;
   if (variant == 1 && staged_ok) {
-    int fpb = 16;
+    static const int fpb_max = getenv("RCC_INGEST_FPB") ? atoi(getenv("RCC_INGEST_FPB")) : 32;
+    int fpb = fpb_max;
     const int tiles = ((w + ST_TW - 1) / ST_TW) * ((ht + ST_TH - 1) / ST_TH);
     while (fpb > 2 && (int64_t)tiles * ((nframes + fpb - 1) / fpb) < 4096) fpb >>= 1;
-    dim3 grid((w + ST_TW - 1) / ST_TW, (ht + ST_TH - 1) / ST_TH, (nframes + fpb - 1) / fpb);
+    const int ntx = (w + ST_TW - 1) / ST_TW, per_xcd = (tiles + 7) / 8, ngroups = (nframes + fpb - 1) / fpb;
+    dim3 grid(8 * per_xcd * ngroups);
     if (c.pixfmt == RCC_PIX_BGR8)
-      hipLaunchKernelGGL((k_ingest_staged<3>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb);
+      hipLaunchKernelGGL((k_ingest_staged<3>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb, ntx, tiles, per_xcd);
     else
-      hipLaunchKernelGGL((k_ingest_staged<1>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb);
+      hipLaunchKernelGGL((k_ingest_staged<1>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb, ntx, tiles, per_xcd);
     return hipGetLastError();
   }
   // frames per block: amortise the fp64 map; keep >= ~2048 blocks in flight
