@@ -1,0 +1,196 @@
+// dense_rows.h -- the per-lane row pipeline of the threshold + corner pass (a3 + a4.1), shared by the two
+// row-marching kernels (k_dense_fast.hip: one wave per strip, registers only; k_dense_band.hip: one workgroup
+// per full-width band, grey rows staged through LDS).  Definitions: DESIGN.md section 3; bit-exact with
+// k_dense_lds (k_dense.hip) and with oracle/orc_image.c.
+//
+// Lane layout: a wavefront covers a 256-pixel window, lane l holds the 4 pixels x0 .. x0+3 (one dword of the
+// grey row); lanes 0, 1 and 63 are halo (the left lattice neighbour of the first useful pixel needs 5 pixels),
+// so a window has 244 useful pixels.  Neighbouring lanes exchange edge values with whole-wave DPP shifts.
+#pragma once
+#include "rcc_internal.h"
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+#define DPP_FROM_LEFT 0x138   // wave_shr:1 : lane l reads lane l-1
+#define DPP_FROM_RIGHT 0x130  // wave_shl:1 : lane l reads lane l+1
+#define STRIP_USE 244         // useful pixels per window: lanes 2..62
+
+__device__ __forceinline__ int from_left(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, DPP_FROM_LEFT, 0xf, 0xf, false); }
+__device__ __forceinline__ int from_right(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, DPP_FROM_RIGHT, 0xf, 0xf, false); }
+// zero for lanes without a source (bound_ctrl:0): lets the compiler fold the move into the consumer
+__device__ __forceinline__ int from_left0(int v) { return __builtin_amdgcn_update_dpp(0, v, DPP_FROM_LEFT, 0xf, 0xf, true); }
+__device__ __forceinline__ int from_right0(int v) { return __builtin_amdgcn_update_dpp(0, v, DPP_FROM_RIGHT, 0xf, 0xf, true); }
+__device__ __forceinline__ i16x2 as_i(unsigned v) { return __builtin_bit_cast(i16x2, v); }
+__device__ __forceinline__ u16x2 as_u(unsigned v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ unsigned bits(i16x2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ unsigned bits(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+
+struct HSum { int xx0, xy0, yy0, xx2, xy2, yy2; };   // raw 5-px row sums at pixel 0 and pixel 2 of the lane
+struct SobelRow { i16x2 dh01, dh23, sh01, sh23; };     // horizontal Sobel partials of one row (pixel pairs 0-1, 2-3)
+struct Tile4 { unsigned g0, g1, g2, g3; };             // grey dwords of the four rows of a tile row
+struct TStat { int hmin, hmax; };                      // horizontally dilated tile min / max
+struct LRow { int r0, r2, rL, rR; };                   // lattice row of responses: own px 0, px 2, left and right neighbour
+
+// "don't care" values that cost no instruction (the compiler may leave anything in the register)
+__device__ __forceinline__ void dontcare(int& v) { asm volatile("" : "=v"(v)); }
+__device__ __forceinline__ void dontcare(SobelRow& q)
+{
+  int a, b, c, d; dontcare(a); dontcare(b); dontcare(c); dontcare(d);
+  q.dh01 = __builtin_bit_cast(i16x2, a); q.dh23 = __builtin_bit_cast(i16x2, b); q.sh01 = __builtin_bit_cast(i16x2, c); q.sh23 = __builtin_bit_cast(i16x2, d);
+}
+__device__ __forceinline__ void dontcare(HSum& q) { dontcare(q.xx0); dontcare(q.xy0); dontcare(q.yy0); dontcare(q.xx2); dontcare(q.xy2); dontcare(q.yy2); }
+
+// horizontally dilated min / max of the lane's 4x4 tile (rows C.g0..g3)
+__device__ __forceinline__ TStat tile_stats(const Tile4& C)
+{
+  u16x2 tmn = (u16x2)(255), tmx = (u16x2)(0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned G = (k == 0) ? C.g0 : (k == 1) ? C.g1 : (k == 2) ? C.g2 : C.g3;
+    const u16x2 n0 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));
+    const u16x2 n1 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C030C02u));
+    tmn = __builtin_elementwise_min(tmn, __builtin_elementwise_min(n0, n1));
+    tmx = __builtin_elementwise_max(tmx, __builtin_elementwise_max(n0, n1));
+  }
+  const int tmin = min((int)tmn.x, (int)tmn.y), tmax = max((int)tmx.x, (int)tmx.y);
+  TStat hn;
+  hn.hmin = min(tmin, min(from_left(tmin, tmin), from_right(tmin, tmin)));
+  hn.hmax = max(tmax, max(from_left(tmax, tmax), from_right(tmax, tmax)));
+  return hn;
+}
+
+// threshold of four pixels: per byte 255 if v > thr else 0; 127 everywhere if the tile is flat.
+// v > thr <=> v >= thr+1 (thr <= 254 whenever the tile is not flat).  SWAR unsigned byte compare:
+// d = (x|H) - (y&~H) has its per-byte MSB set iff the low 7 bits of x >= those of y (no borrow crosses
+// bytes); where the MSBs of x and y differ x's decides, else d's.
+struct Thr4 {
+  unsigned y4, ylo, ny; int flat;
+  __device__ __forceinline__ Thr4(int thr, int flat_) : flat(flat_)
+  {
+    y4 = __builtin_amdgcn_perm(0u, (unsigned)(thr + 1), 0u);   // byte 0 replicated
+    ylo = y4 & 0x7F7F7F7Fu; ny = ~y4;
+  }
+  __device__ __forceinline__ unsigned operator()(unsigned x) const
+  {
+    const unsigned H = 0x80808080u;
+    const unsigned d = (x | H) - ylo;
+    const unsigned xy = x ^ y4;
+    const unsigned ge = (((x & ny) & xy) | (d & ~xy)) & H;      // bitfield select on xy
+    const unsigned o = ge | (ge - (ge >> 7));                    // 0x80 -> 0xFF per byte, no carries
+    return flat ? 0x7F7F7F7Fu : o;
+  }
+};
+
+// the Sobel / structure-tensor / response / selection pipeline of one lane
+struct RowPipe {
+  HSum hprev, qa, qb;          // qa: pair closed at k=0, qb: pair closed at k=2
+  LRow Ra, Rb;                 // lattice rows y-4, y-2
+  // job constants
+  int x0, w, h, t0, t1, margin, hthresh, cap, f, lane;
+  bool lane_out;
+  rcc_cand* cand; int32_t* cand_count;
+
+  __device__ __forceinline__ void reset()
+  {
+    hprev = HSum{ 0, 0, 0, 0, 0, 0 }; qa = hprev; qb = hprev;
+    Ra = LRow{ INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN }; Rb = Ra;
+  }
+  // a skipped tile row: the two lattice rows not produced lie in flat tiles; the row sums now describe rows
+  // that were not read, and everything they can still reach is a masked response, so their contents do not
+  // matter (no copies at the control-flow join)
+  __device__ __forceinline__ void skip()
+  {
+    Ra.r0 = Ra.r2 = Ra.rL = Ra.rR = INT32_MIN; Rb = Ra;
+    dontcare(hprev); dontcare(qa); dontcare(qb);
+  }
+
+  // one image row: G = its grey dword; (a, b) = Sobel partials of rows r-2, r-1; n receives row r's.
+  // rmask != 0: the lane's tile at the lattice row being produced is flat => its response cannot
+  // reach hthresh (host-checked bound), so it is replaced by INT32_MIN
+  __device__ __forceinline__ void row(const int r, const int k, const unsigned G, const SobelRow& a, const SobelRow& b, SobelRow& n, const int rmask)
+  {
+    // ---- stage A (row r): horizontal Sobel partials, natural-order pixel pairs
+    const unsigned GL = (unsigned)from_left((int)G, (int)G), GR = (unsigned)from_right((int)G, (int)G);
+    const u16x2 n0 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));    // [p0,p1]
+    const u16x2 n1 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C030C02u));    // [p2,p3]
+    const u16x2 mm = as_u(__builtin_amdgcn_perm(0u, G, 0x0C020C01u));    // [p1,p2]
+    const u16x2 lh = as_u(__builtin_amdgcn_perm(GL, G, 0x0C000C07u));    // [p-1,p0]
+    const u16x2 rh = as_u(__builtin_amdgcn_perm(GR, G, 0x0C040C03u));    // [p3,p4]
+    const i16x2 two = (i16x2)(2);
+    n.dh01 = as_i(bits(mm)) - as_i(bits(lh));                            // I[x+1]-I[x-1] for x = p0,p1
+    n.dh23 = as_i(bits(rh)) - as_i(bits(mm));
+    n.sh01 = as_i(bits(n0)) * two + as_i(bits(lh)) + as_i(bits(mm));     // I[x-1]+2I[x]+I[x+1]
+    n.sh23 = as_i(bits(n1)) * two + as_i(bits(mm)) + as_i(bits(rh));
+    // ---- stage B (row rho = r-1): gradients
+    const i16x2 gx01 = (b.dh01 * two + a.dh01 + n.dh01) >> 3;
+    const i16x2 gx23 = (b.dh23 * two + a.dh23 + n.dh23) >> 3;
+    const i16x2 gy01 = (n.sh01 - a.sh01) >> 3;
+    const i16x2 gy23 = (n.sh23 - a.sh23) >> 3;
+    // ---- stage C (row rho): products + horizontal 5-sums at pixels 0 and 2
+    const int d0xx = __builtin_amdgcn_sdot2(gx01, gx01, 0, false);
+    const int d0xy = __builtin_amdgcn_sdot2(gx01, gy01, 0, false);
+    const int d0yy = __builtin_amdgcn_sdot2(gy01, gy01, 0, false);
+    const int d1xx = __builtin_amdgcn_sdot2(gx23, gx23, 0, false);
+    const int d1xy = __builtin_amdgcn_sdot2(gx23, gy23, 0, false);
+    const int d1yy = __builtin_amdgcn_sdot2(gy23, gy23, 0, false);
+    const int ax0 = gx01.x, ay0 = gy01.x, ax2 = gx23.x, ay2 = gy23.x;
+    const int q0xx = __mul24(ax0, ax0), q0xy = __mul24(ax0, ay0), q0yy = __mul24(ay0, ay0);
+    const int q2xx = __mul24(ax2, ax2), q2xy = __mul24(ax2, ay2), q2yy = __mul24(ay2, ay2);
+    HSum hc;
+    hc.xx0 = d0xx + q2xx + from_left0(d1xx);
+    hc.xy0 = d0xy + q2xy + from_left0(d1xy);
+    hc.yy0 = d0yy + q2yy + from_left0(d1yy);
+    hc.xx2 = d0xx + d1xx + from_right0(q0xx);
+    hc.xy2 = d0xy + d1xy + from_right0(q0xy);
+    hc.yy2 = d0yy + d1yy + from_right0(q0yy);
+    // ---- stage D/E/F: vertical sums on the lattice, response, selection
+    if ((k & 1) == 0) {
+      // rho = r-1 is odd: close the pair (rho-1, rho) into qa (k = 0) or qb (k = 2)
+      HSum& q = (k == 0) ? qa : qb;
+      q.xx0 = hprev.xx0 + hc.xx0; q.xy0 = hprev.xy0 + hc.xy0; q.yy0 = hprev.yy0 + hc.yy0;
+      q.xx2 = hprev.xx2 + hc.xx2; q.xy2 = hprev.xy2 + hc.xy2; q.yy2 = hprev.yy2 + hc.yy2;
+    } else {
+      // rho = r-1 is even: 5-row sums centred on y = rho-2 = the two closed pairs + this row
+      const int A0 = (qa.xx0 + qb.xx0 + hc.xx0) >> 4, B0 = (qa.xy0 + qb.xy0 + hc.xy0) >> 4, C0 = (qa.yy0 + qb.yy0 + hc.yy0) >> 4;
+      const int A2 = (qa.xx2 + qb.xx2 + hc.xx2) >> 4, B2 = (qa.xy2 + qb.xy2 + hc.xy2) >> 4, C2 = (qa.yy2 + qb.yy2 + hc.yy2) >> 4;
+      const unsigned tr0 = (unsigned)(A0 + C0), tr2 = (unsigned)(A2 + C2);
+      LRow Rn;
+      Rn.r0 = rmask ? INT32_MIN : __mul24(A0, C0) - __mul24(B0, B0) - (int)(__umul24(tr0, tr0) >> 4);
+      Rn.r2 = rmask ? INT32_MIN : __mul24(A2, C2) - __mul24(B2, B2) - (int)(__umul24(tr2, tr2) >> 4);
+      Rn.rL = from_left(Rn.r2, INT32_MIN);
+      Rn.rR = from_right(Rn.r0, INT32_MIN);
+      hprev = hc;
+      // selection on lattice row yc = rho - 4 = r - 5 (rows Ra = yc-2, Rb = yc, Rn = yc+2)
+      const int yc = r - 5;
+      const bool rowok = (yc >= 4 * t0) && (yc < 4 * t1) && (yc >= margin) && (yc < h - margin);
+      if (rowok && __any((Rb.r0 >= hthresh) || (Rb.r2 >= hthresh))) {
+        const int xa = x0, xb = x0 + 2;
+        bool is0 = lane_out && Rb.r0 >= hthresh && xa >= margin && xa < w - margin &&
+                   Rb.r0 > Ra.rL && Rb.r0 > Ra.r0 && Rb.r0 > Ra.r2 && Rb.r0 > Rb.rL &&
+                   Rb.r0 >= Rb.r2 && Rb.r0 >= Rn.rL && Rb.r0 >= Rn.r0 && Rb.r0 >= Rn.r2;
+        bool is2 = lane_out && Rb.r2 >= hthresh && xb >= margin && xb < w - margin &&
+                   Rb.r2 > Ra.r0 && Rb.r2 > Ra.r2 && Rb.r2 > Ra.rR && Rb.r2 > Rb.r0 &&
+                   Rb.r2 >= Rb.rR && Rb.r2 >= Rn.r0 && Rb.r2 >= Rn.r2 && Rb.r2 >= Rn.rR;
+        const unsigned long long m0 = __ballot(is0), m2 = __ballot(is2);
+        const int n0c = __popcll(m0), n2c = __popcll(m2);
+        if (n0c + n2c) {
+          int basei = 0;
+          if (lane == 0) basei = atomicAdd(&cand_count[f], n0c + n2c);
+          basei = __shfl(basei, 0);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (is0) {
+            int idx = basei + __popcll(m0 & below);
+            if (idx < cap) { rcc_cand e; e.x = (int16_t)xa; e.y = (int16_t)yc; e.score = Rb.r0; cand[(size_t)f * cap + idx] = e; }
+          }
+          if (is2) {
+            int idx = basei + n0c + __popcll(m2 & below);
+            if (idx < cap) { rcc_cand e; e.x = (int16_t)xb; e.y = (int16_t)yc; e.score = Rb.r2; cand[(size_t)f * cap + idx] = e; }
+          }
+        }
+      }
+      Ra = Rb;
+      Rb = Rn;
+    }
+  }
+};

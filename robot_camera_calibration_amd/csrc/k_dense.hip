@@ -193,10 +193,15 @@ __global__ __launch_bounds__(256) void k_dense_lds(const uint8_t* __restrict__ g
   }
 }
 
-hipError_t rcc_launch_dense_fast(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
+hipError_t rcc_launch_dense_march(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
+                                  rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
+bool rcc_dense_march_supported(const rcc_handle* h);
+hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
                                  rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
-bool rcc_dense_fast_supported(const rcc_handle* h);
+bool rcc_dense_band_supported(const rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin);
 
+// variants: 0 = generic LDS tiles (any geometry), 1 = band kernel (k_dense_band.hip), 2 = strip march
+// (k_dense_fast.hip); -1 = the fastest one the geometry allows.  All three produce identical outputs.
 hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
                             rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s)
 {
@@ -205,9 +210,12 @@ hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, u
   hipError_t e = hipMemsetAsync(d_cand_count, 0, sizeof(int32_t) * (size_t)nframes, s);
   if (e != hipSuccess) return e;
   int variant = h->dense_variant;
-  if (variant < 0) variant = rcc_dense_fast_supported(h) ? 1 : 0;
-  if (variant == 1 && rcc_dense_fast_supported(h))
-    return rcc_launch_dense_fast(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s);
+  const bool band_ok = rcc_dense_band_supported(h, d_grey, d_bin), march_ok = rcc_dense_march_supported(h);
+  if (variant < 0) variant = band_ok ? 1 : (march_ok ? 2 : 0);
+  if (variant == 1 && !band_ok) variant = march_ok ? 2 : 0;
+  if (variant == 2 && !march_ok) variant = 0;
+  if (variant == 1) return rcc_launch_dense_band(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s);
+  if (variant == 2) return rcc_launch_dense_march(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s);
   const int w = c.width, ht = c.height;
   int tw = w >> 2, th = ht >> 2;
   if (tw < 1) tw = 1;
@@ -217,12 +225,4 @@ hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, u
   hipLaunchKernelGGL(k_dense_lds, grid, dim3(256), 0, s, d_grey, w, ht, nbx, nby, c.thr_min_contrast,
                      c.harris_thresh, c.cand_margin, c.max_candidates, d_bin, d_cand, d_cand_count);
   return hipGetLastError();
-}
-
-// The row-marching fast kernel lands in k_dense_fast.hip; until it exists this reports "not
-// supported" so the generic kernel serves every geometry.
-__attribute__((weak)) bool rcc_dense_fast_supported(const rcc_handle*) { return false; }
-__attribute__((weak)) hipError_t rcc_launch_dense_fast(rcc_handle*, const uint8_t*, int, uint8_t*, rcc_cand*, int32_t*, hipStream_t)
-{
-  return hipErrorNotSupported;
 }

@@ -244,32 +244,39 @@ def test_edge_cases(torch_cuda, oracle):
         api.Detector(bad)
 
 
-@pytest.mark.parametrize("pixfmt", [abi.RCC_PIX_BGR8, abi.RCC_PIX_MONO8])
-def test_kernel_variants_bit_identical(torch_cuda, oracle, pixfmt):
+# dense pass: (variant, flat-row skip) -- 0 generic LDS tiles, 1 band kernel, 2 strip march
+DENSE_VARIANTS = ((0, 1), (1, 1), (1, 0), (2, 1), (2, 0))
+
+
+@pytest.mark.parametrize("pixfmt,w,h,n", [(abi.RCC_PIX_BGR8, 640, 480, 5), (abi.RCC_PIX_MONO8, 640, 480, 5),
+                                          (abi.RCC_PIX_BGR8, 1920, 1080, 3), (abi.RCC_PIX_MONO8, 3840, 2160, 2),
+                                          (abi.RCC_PIX_MONO8, 2064, 1160, 2)])
+def test_kernel_variants_bit_identical(torch_cuda, oracle, pixfmt, w, h, n):
     """generic vs fast variants of the ingest and dense passes: same bytes, same candidate sets,
-    and both equal to the oracle"""
+    and all equal to the oracle.  Sizes: one band with idle waves (640), one full band (1920), two
+    bands (3840: the second band's staged image starts 128 columns left of it), a second band of 144 columns (2064)."""
     torch = torch_cuda
-    n = 5
-    cfg = _make(w=640, h=480, pixfmt=pixfmt, B=n)
+    cfg = _make(w=w, h=h, pixfmt=pixfmt, B=n)
     det = api.Detector(cfg)
     frames, _ = _render(torch, det, cfg, n, seed=99)
     px = cfg.width * cfg.height
     outs = {}
     for iv in (0, 1):
-        for dv in (0, 1, 2):      # 2 = fast kernel with the flat-row skip disabled
+        for dv in DENSE_VARIANTS:
             det.set_ingest_variant(iv)
-            det.set_dense_variant(min(dv, 1))
-            det.set_dense_skip(0 if dv == 2 else 1)
+            det.set_dense_variant(dv[0])
+            det.set_dense_skip(dv[1])
             grey = torch.zeros((n, px), dtype=torch.uint8, device="cuda:0")
             binm = torch.zeros((n, px), dtype=torch.uint8, device="cuda:0")
             cand = torch.zeros((n, cfg.max_candidates * 8), dtype=torch.uint8, device="cuda:0")
             cnt = torch.zeros((n,), dtype=torch.int32, device="cuda:0")
+            torch.cuda.synchronize()      # the fills run on torch's stream, the stages on the detector's own
             det.stage_ingest(frames, n, grey)
             det.stage_threshold_corner(grey, n, binm, cand, cnt)
             c = cand.cpu().numpy().view(api.CAND_DT).reshape(n, cfg.max_candidates)
             k = cnt.cpu().numpy()
             outs[(iv, dv)] = (grey.cpu().numpy(), binm.cpu().numpy(), [sorted_cands(c[f][:k[f]]) for f in range(n)], k)
-    ref = outs[(0, 0)]
+    ref = outs[(0, DENSE_VARIANTS[0])]
     for key, o in outs.items():
         assert (o[0] == ref[0]).all(), "grey differs for variant %s" % (key,)
         assert (o[1] == ref[1]).all(), "threshold map differs for variant %s" % (key,)
