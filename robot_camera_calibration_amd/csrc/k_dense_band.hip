@@ -51,7 +51,7 @@ __device__ __forceinline__ void dma_1k(i32x4 rsrc, unsigned lds_addr, int voff, 
                : "memory");
 }
 
-template <int MODE>   // 0: the pass; 1: its data movement only (experiment)
+template <int MODE, int PRIO>   // MODE 0: the pass; 1: its data movement only (experiment).  PRIO: raise the priority of computing waves
 __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ grey, int w, int h,
                                                     int nbands, int nseg, int seg_tiles, int nframes,
                                                     int min_contrast, int hthresh, int margin, int cap, int allow_skip,
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
   auto flush = [&](int tt, int buf) {
     const bool ok = (tt >= t0) && (tt < t1);                   // scalar
     const u32x4 q = *reinterpret_cast<const u32x4*>(obuf + buf * BAND_OBUF + fl_rd);
-    __builtin_amdgcn_raw_buffer_store_b128(q, rs_b, ok ? fl_voff : BAND_INVALID, ok ? 4 * tt * w : 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs_b, ok ? fl_voff : BAND_INVALID, __builtin_amdgcn_readfirstlane(ok ? 4 * tt * w : 0), 0);
   };
   auto read_tile = [&](int slot) -> Tile4 {
     const uint8_t* p = ring + slot * BAND_SLOT + rd_off;
@@ -167,6 +167,7 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
       const int tau = t - 2;
       if (tau >= t0 - 2) {
         if (__any(!(Fa && Fb && Fn))) {
+          if (PRIO) __builtin_amdgcn_s_setprio(2);          // the wave on the critical path of this iteration
           const Tile4 B = read_tile(sb2);
           const Thr4 thr(thrB, flatB);
           stage_out(ob, thr(B.g0), thr(B.g1), thr(B.g2), thr(B.g3));
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
           P.row(4 * tau + 1, 1, B.g1, sb, sc, sa, Fa);     // produces lattice row 4*tau-2, in tile row tau-1
           P.row(4 * tau + 2, 2, B.g2, sc, sa, sb, 0);
           P.row(4 * tau + 3, 3, B.g3, sa, sb, sc, Fb);     // produces lattice row 4*tau, in tile row tau
+          if (PRIO) __builtin_amdgcn_s_setprio(0);
         } else {
           stage_out(ob, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
           P.skip();
@@ -226,17 +228,22 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
   // segments: ~8 workgroups per resident slot (2 per CU) over the launch, at least 16 tile rows each so that the
   // 4 warm-up / drain iterations stay a small fraction
   int seg_tiles = th;
-  const long long want = 256LL * 2 * 8;
+  static const long long want_mul = getenv("RCC_DENSE_WANT") ? atoll(getenv("RCC_DENSE_WANT")) : 4;
+  const long long want = 256LL * 2 * want_mul;
   while (seg_tiles > 16 && (long long)nbands * nframes * ((th + seg_tiles - 1) / seg_tiles) < want) seg_tiles = (seg_tiles + 1) / 2;
   const int nseg = (th + seg_tiles - 1) / seg_tiles;
   const int allow_skip = rcc_dense_allow_skip(h);
   const long long njobs = (long long)nbands * nseg * nframes;
   static const int memonly = getenv("RCC_DENSE_MEMONLY") ? atoi(getenv("RCC_DENSE_MEMONLY")) : 0;
+  static const int prio = getenv("RCC_DENSE_PRIO") ? atoi(getenv("RCC_DENSE_PRIO")) : 1;
   if (memonly)
-    hipLaunchKernelGGL(k_dense_band<1>, dim3((unsigned)njobs), dim3(512), 0, s, d_grey, w, ht, nbands, nseg, seg_tiles, nframes,
+    hipLaunchKernelGGL((k_dense_band<1, 0>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, w, ht, nbands, nseg, seg_tiles, nframes,
+                       c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
+  else if (prio)
+    hipLaunchKernelGGL((k_dense_band<0, 1>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, w, ht, nbands, nseg, seg_tiles, nframes,
                        c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
   else
-    hipLaunchKernelGGL(k_dense_band<0>, dim3((unsigned)njobs), dim3(512), 0, s, d_grey, w, ht, nbands, nseg, seg_tiles, nframes,
+    hipLaunchKernelGGL((k_dense_band<0, 0>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, w, ht, nbands, nseg, seg_tiles, nframes,
                        c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
   return hipGetLastError();
 }
