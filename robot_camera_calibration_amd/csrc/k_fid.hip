@@ -321,8 +321,9 @@ __global__ __launch_bounds__(64) void k_pnp_tags(rcc_detection* __restrict__ det
   for (int i = 0; i < 5; ++i) cm.k[i] = cam.D[i];
   cm.solver = cam.solver;
   double r[3], tv[3], e = 0.0;
+  double wsl[rccpnp::PNP_WS];
   int it = 0;
-  const int st = rccpnp::solve_pnp(rccpnp::SerialPar(), p, cm, cam.model, r, tv, &e, &it);
+  const int st = rccpnp::solve_pnp(rccpnp::SerialPar{ wsl }, p, cm, cam.model, r, tv, &e, &it);
   for (int c = 0; c < 3; ++c) { d->rvec[c] = r[c]; d->tvec[c] = tv[c]; }
   d->rms = e; d->pnp_status = st; d->pnp_iters = it;
 }

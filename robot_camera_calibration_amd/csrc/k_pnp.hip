@@ -38,8 +38,9 @@ __global__ __launch_bounds__(64) void k_pnp_generic(const double* __restrict__ o
   if (t >= ntargets) return;
   rccpnp::Pts p{ obj + 3 * (size_t)off[t], img + 2 * (size_t)off[t], npts[t] };
   double r[3], tv[3], e = 0.0;
+  double wsl[rccpnp::PNP_WS];
   int it = 0;
-  int st = rccpnp::solve_pnp(rccpnp::SerialPar(), p, to_cam(cam), cam.model, r, tv, &e, &it);
+  int st = rccpnp::solve_pnp(rccpnp::SerialPar{ wsl }, p, to_cam(cam), cam.model, r, tv, &e, &it);
   for (int k = 0; k < 3; ++k) { rvec[3 * t + k] = r[k]; tvec[3 * t + k] = tv[k]; }
   if (rms) rms[t] = e;
   if (status) status[t] = st;
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(64) void k_pnp_board(const rcc_frame_corners* __res
   const int idx[4] = { (rows - 1) * cols, (rows - 1) * cols + cols - 1, cols - 1, 0 };   // bl, br, tr, tl
   for (int k = 0; k < 4; ++k) { d.corners[k][0] = c->xy[idx[k]][0]; d.corners[k][1] = c->xy[idx[k]][1]; }
   int it = 0;
-  d.pnp_status = rccpnp::solve_pnp(rccpnp::SerialPar(), p, to_cam(cam), cam.model, d.rvec, d.tvec, &d.rms, &it);
+  double wsl[rccpnp::PNP_WS];
+  d.pnp_status = rccpnp::solve_pnp(rccpnp::SerialPar{ wsl }, p, to_cam(cam), cam.model, d.rvec, d.tvec, &d.rms, &it);
   d.pnp_iters = it;
   det[f] = d;
   ndet[f] = 1;
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* 
   }
   __syncthreads();
   rccpnp::Pts p{ board_obj, img, need };
-  rccpnp::WavePar par{ lane };
+  __shared__ double ws[rccpnp::PNP_WS];          // the wave-uniform matrices: one copy per wavefront, in LDS
+  rccpnp::WavePar par{ lane, ws };
   double r[3], tv[3], e = 0.0;
   int it = 0;
   const int st = rccpnp::solve_pnp(par, p, to_cam(cam), cam.model, r, tv, &e, &it);
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(64) void k_pnp_generic_wave(const double* __restric
   const int t = blockIdx.x;
   const int lane = threadIdx.x;
   rccpnp::Pts p{ obj + 3 * (size_t)off[t], img + 2 * (size_t)off[t], npts[t] };
-  rccpnp::WavePar par{ lane };
+  __shared__ double ws[rccpnp::PNP_WS];
+  rccpnp::WavePar par{ lane, ws };
   double r[3], tv[3], e = 0.0;
   int it = 0;
   int st = rccpnp::solve_pnp(par, p, to_cam(cam), cam.model, r, tv, &e, &it);
@@ -153,7 +157,8 @@ __global__ void k_pnp_probe(const double* obj, const double* img, int n, rcc_cam
   rccpnp::Cam cm = to_cam(cam);
   const bool has_dist = cam.model == RCC_DIST_PLUMB_BOB;
   if (!has_dist) for (int i = 0; i < 5; ++i) cm.k[i] = 0.0;
-  rccpnp::SerialPar par;
+  double wsl[rccpnp::PNP_WS];
+  rccpnp::SerialPar par{ wsl };
   double Rt[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, Tt[3] = { 0, 0, 0 };
   double H[9];
   int ok = rccpnp::find_homography(par, p, Rt, Tt, cm, has_dist, H);

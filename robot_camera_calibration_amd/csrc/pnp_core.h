@@ -176,10 +176,9 @@ RCC_NI RCC_HD inline void sym_solve(int n, const double* A, const double* b, dou
 // the solutions agree to ~1e-12 relative.  A pivot below 1e-13 of the largest diagonal entry means
 // the SVD path would have dropped a direction: then fall back to sym_solve, which does.
 template <int N>
-RCC_HD inline void spd_solve(int solver, const double* A, const double* b, double* x)
+RCC_HD inline void spd_solve(int solver, const double* A, const double* b, double* x, double* L /* N*N workspace */)
 {
   bool ok = (solver != 0);
-  double L[N * N];
   if (ok) {
     double dmax = 0.0;
 #pragma unroll
@@ -239,9 +238,8 @@ RCC_HD inline void spd_solve(int solver, const double* A, const double* b, doubl
 // takes this vector from a full eigen-decomposition (A.4); the vector is the same up to sign, and
 // the homography is normalised by H[2][2] afterwards.
 template <int N>
-RCC_HD inline int smallest_eigvec_psd(const double* M, double* x /* N */)
+RCC_HD inline int smallest_eigvec_psd(const double* M, double* x /* N */, double* L /* N*N workspace */)
 {
-  double L[N * N];
   double tr = 0.0;
 #pragma unroll
   for (int i = 0; i < N; ++i) tr += M[i * N + i];
@@ -298,7 +296,14 @@ RCC_HD inline int smallest_eigvec_psd(const double* M, double* x /* N */)
 // How the per-point loops are spread: serially in one thread, or over the 64 lanes of a wavefront
 // (each lane takes points lane, lane+64, ...; sums are combined by an xor butterfly so that every
 // lane ends up with the same value and the scalar algebra that follows stays wave-uniform).
+// Both carry `w`: a workspace of PNP_WS doubles for the wave-uniform matrices (normal equations, Cholesky
+// factors).  One copy per solver instance: per thread for SerialPar, per wavefront (in LDS) for WavePar --
+// replicated in the registers of 64 lanes these matrices spill to scratch, and every spilled access costs a
+// memory round trip on the solver's single dependency chain.
+enum { PNP_WS = 256 };
 struct SerialPar {
+  double* w;
+  RCC_HD double* ws() const { return w; }
   RCC_HD int first() const { return 0; }
   RCC_HD int step() const { return 1; }
   RCC_HD double sum(double v) const { return v; }
@@ -307,6 +312,8 @@ struct SerialPar {
 #ifdef __HIPCC__
 struct WavePar {
   int lane;
+  double* w;
+  __device__ double* ws() const { return w; }
   __device__ int first() const { return lane; }
   __device__ int step() const { return 64; }
   __device__ double sum(double v) const {
@@ -514,7 +521,13 @@ template <class Par>
 RCC_HD inline double homography_accumulate(const Par& par, const double* h, const Pts& p, const double* Rt, const double* Tt,
                                            const Cam& cm, bool has_dist, double* A, double* v, double* rinf)
 {
-  if (A) { for (int i = 0; i < 64; ++i) A[i] = 0.0; for (int i = 0; i < 8; ++i) v[i] = 0.0; }
+  double al[36], vl[8];                       // this lane's share of JtJ (upper triangle, row-major) and Jtr
+  if (A) {
+#pragma unroll
+    for (int i = 0; i < 36; ++i) al[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vl[i] = 0.0;
+  }
   double S = 0.0, ri = 0.0;
   for (int i = par.first(); i < p.n; i += par.step()) {
     float Mxf, Myf, mxf, myf;
@@ -534,10 +547,10 @@ RCC_HD inline double homography_accumulate(const Par& par, const double* h, cons
       double a[8] = { Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi };
       double b[8] = { 0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi };
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
+      for (int r = 0, k = 0; r < 8; ++r) {
 #pragma unroll
-        for (int c = r; c < 8; ++c) A[r * 8 + c] += a[r] * a[c] + b[r] * b[c];
-        v[r] += a[r] * e0 + b[r] * e1;
+        for (int c = r; c < 8; ++c, ++k) al[k] += a[r] * a[c] + b[r] * b[c];
+        vl[r] += a[r] * e0 + b[r] * e1;
       }
     }
   }
@@ -545,10 +558,10 @@ RCC_HD inline double homography_accumulate(const Par& par, const double* h, cons
   if (rinf) *rinf = par.max(ri);
   if (A) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0, k = 0; r < 8; ++r) {
 #pragma unroll
-      for (int c = r; c < 8; ++c) { A[r * 8 + c] = par.sum(A[r * 8 + c]); A[c * 8 + r] = A[r * 8 + c]; }
-      v[r] = par.sum(v[r]);
+      for (int c = r; c < 8; ++c, ++k) { const double t = par.sum(al[k]); A[r * 8 + c] = t; A[c * 8 + r] = t; }
+      v[r] = par.sum(vl[r]);
     }
   }
   return S;
@@ -560,7 +573,10 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
 {
   const int P = 8, maxIters = 10;
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
-  double x[8], xd[8], A[64], Ap[64], v[8], d[8], Dg[8], tmp[8];
+  double x[8], xd[8], v[8], d[8], Dg[8], tmp[8];
+  double* const A = par.ws();                 // 64
+  double* const Ap = par.ws() + 64;           // 64
+  double* const Lw = par.ws() + 128;          // 64: Cholesky factor
 #pragma unroll
   for (int i = 0; i < 8; ++i) x[i] = h[i];
   double rinf = 0.0;
@@ -575,7 +591,7 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
     for (int i = 0; i < 64; ++i) Ap[i] = A[i];
 #pragma unroll
     for (int i = 0; i < P; ++i) Ap[i * P + i] += lambda * Dg[i];
-    spd_solve<8>(cm.solver, Ap, v, d);
+    spd_solve<8>(cm.solver, Ap, v, d, Lw);
 #pragma unroll
     for (int i = 0; i < P; ++i) xd[i] = x[i] - d[i];
     double Sd = homography_accumulate(par, xd, p, Rt, Tt, cm, has_dist, (double*)nullptr, (double*)nullptr, (double*)nullptr);
@@ -599,7 +615,9 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
       double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1.0) + 2.0;
       nu = nu < 2.0 ? 2.0 : (nu > 10.0 ? 10.0 : nu);
       if (lambda == 0.0) {
-        double T[64], V[64], w[8];
+        double* const T = par.ws() + 64;      // Ap and the factor are dead here
+        double* const V = par.ws() + 128;
+        double w[8];
 #pragma unroll
         for (int i = 0; i < 64; ++i) T[i] = A[i];
         jacobi_eigen_sym(P, T, w, V);
@@ -662,9 +680,10 @@ RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const dou
   smx = n / smx; smy = n / smy; sMx = n / sMx; sMy = n / sMy;
   double invHnorm[9] = { 1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1 };
   double Hnorm2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
-  double LtL[81];
+  double* const LtL = par.ws();               // 81
+  double ll[45];                              // this lane's share, upper triangle row-major
 #pragma unroll
-  for (int i = 0; i < 81; ++i) LtL[i] = 0.0;
+  for (int i = 0; i < 45; ++i) ll[i] = 0.0;
   for (int i = par.first(); i < n; i += par.step()) {
     float Mxf, Myf, mxf, myf;
     plane_point(p, i, Rt, Tt, Mxf, Myf);
@@ -674,19 +693,19 @@ RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const dou
     double Lx[9] = { X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x };
     double Ly[9] = { 0, 0, 0, X, Y, 1, -y * X, -y * Y, -y };
 #pragma unroll
-    for (int j = 0; j < 9; ++j)
+    for (int j = 0, q = 0; j < 9; ++j)
 #pragma unroll
-      for (int k = j; k < 9; ++k) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+      for (int k = j; k < 9; ++k, ++q) ll[q] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
   }
 #pragma unroll
-  for (int j = 0; j < 9; ++j)
+  for (int j = 0, q = 0; j < 9; ++j)
 #pragma unroll
-    for (int k = j; k < 9; ++k) { LtL[j * 9 + k] = par.sum(LtL[j * 9 + k]); LtL[k * 9 + j] = LtL[j * 9 + k]; }
+    for (int k = j; k < 9; ++k, ++q) { const double t = par.sum(ll[q]); LtL[j * 9 + k] = t; LtL[k * 9 + j] = t; }
   double H0[9], T[9];
-  if (!(cm.solver == 1 && smallest_eigvec_psd<9>(LtL, H0))) {
-    double L2[81], w[9], V[81];                       // full decomposition (as published / fallback): private copies
-#pragma unroll
-    for (int k = 0; k < 81; ++k) L2[k] = LtL[k];
+  if (!(cm.solver == 1 && smallest_eigvec_psd<9>(LtL, H0, par.ws() + 81))) {
+    double* const L2 = LtL;                           // full decomposition (as published / fallback), in place
+    double* const V = par.ws() + 81;
+    double w[9];
     jacobi_eigen_sym(9, L2, w, V);
 #pragma unroll
     for (int k = 0; k < 9; ++k) H0[k] = V[8 * 9 + k];
@@ -709,7 +728,13 @@ RCC_HD inline double pose_accumulate(const Par& par, const double* prm, const Pt
 {
   double R[9], dRdr[27];
   rodrigues_v2m(prm, R, A ? dRdr : nullptr);
-  if (A) { for (int i = 0; i < 36; ++i) A[i] = 0.0; for (int i = 0; i < 6; ++i) g[i] = 0.0; }
+  double al[21], gl[6];                       // this lane's share of JtJ (upper triangle, row-major) and Jte
+  if (A) {
+#pragma unroll
+    for (int i = 0; i < 21; ++i) al[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gl[i] = 0.0;
+  }
   double S = 0.0;
   for (int i = par.first(); i < p.n; i += par.step()) {
     double uv[2], Ju[6], Jv[6];
@@ -719,20 +744,20 @@ RCC_HD inline double pose_accumulate(const Par& par, const double* prm, const Pt
     S += e1 * e1;
     if (A) {
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
+      for (int a = 0, k = 0; a < 6; ++a) {
 #pragma unroll
-        for (int b = a; b < 6; ++b) A[a * 6 + b] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
-        g[a] += Ju[a] * e0 + Jv[a] * e1;
+        for (int b = a; b < 6; ++b, ++k) al[k] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+        gl[a] += Ju[a] * e0 + Jv[a] * e1;
       }
     }
   }
   S = par.sum(S);
   if (A) {
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
+    for (int a = 0, k = 0; a < 6; ++a) {
 #pragma unroll
-      for (int b = a; b < 6; ++b) { A[a * 6 + b] = par.sum(A[a * 6 + b]); A[b * 6 + a] = A[a * 6 + b]; }
-      g[a] = par.sum(g[a]);
+      for (int b = a; b < 6; ++b, ++k) { const double t = par.sum(al[k]); A[a * 6 + b] = t; A[b * 6 + a] = t; }
+      g[a] = par.sum(gl[a]);
     }
   }
   return S;
@@ -809,9 +834,12 @@ RCC_NI RCC_HD inline int pose_init(const Par& par, const Pts& p, const Cam& cm, 
 // A, g when A != null -- it is the only place the points are touched, so a caller can supply a
 // wave-parallel (or MFMA) accumulation.
 template <class Accum>
-RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* rms_sq_sum)
+RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* rms_sq_sum, double* ws /* PNP_WS */)
 {
-  double pprev[6], A[36], g[6], Ap[36], dl[6];
+  double pprev[6], g[6], dl[6];
+  double* const A = ws;                       // 36
+  double* const Ap = ws + 36;                 // 36
+  double* const Lw = ws + 72;                 // 36: Cholesky factor
   int L = -3, it = 0;
   double prevErr = 0.0;
   const int max_iter = 20;
@@ -828,7 +856,7 @@ RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* r
       for (int i = 0; i < 36; ++i) Ap[i] = A[i];
 #pragma unroll
       for (int a = 0; a < 6; ++a) Ap[a * 6 + a] *= 1.0 + lambda;
-      spd_solve<6>(solver, Ap, g, dl);
+      spd_solve<6>(solver, Ap, g, dl, Lw);
 #pragma unroll
       for (int a = 0; a < 6; ++a) p[a] = pprev[a] - dl[a];
       errNorm = sqrt(accum(p, (double*)nullptr, (double*)nullptr));
@@ -874,7 +902,7 @@ RCC_HD inline int solve_pnp(const Par& par, const Pts& p, const Cam& cm_in, int 
   }
   ParAccum<Par> acc{ par, p, cm };
   double ss = 0.0;
-  int it = pose_lm(prm, acc, cm.solver, &ss);
+  int it = pose_lm(prm, acc, cm.solver, &ss, par.ws());
   for (int k = 0; k < 3; ++k) { rvec[k] = prm[k]; tvec[k] = prm[3 + k]; }
   if (rms) *rms = sqrt(ss / p.n);
   if (iters) *iters = it;

@@ -9,7 +9,8 @@ extern "C" int pnpcore_solve(const double* obj, const double* img, int n, const 
   cm.fx = K[0]; cm.cx = K[2]; cm.fy = K[4]; cm.cy = K[5];
   for (int i = 0; i < 5; ++i) cm.k[i] = D[i];
   cm.solver = 1;
-  return rccpnp::solve_pnp(rccpnp::SerialPar(), p, cm, model, rvec, tvec, rms, iters);
+  double wsl[rccpnp::PNP_WS];
+  return rccpnp::solve_pnp(rccpnp::SerialPar{ wsl }, p, cm, model, rvec, tvec, rms, iters);
 }
 extern "C" void pnpcore_rodrigues_v2m(const double* r, double* R, double* J) { rccpnp::rodrigues_v2m(r, R, J); }
 extern "C" void pnpcore_rodrigues_m2v(const double* R, double* r) { rccpnp::rodrigues_m2v(R, r); }
@@ -23,7 +24,8 @@ extern "C" void pnpcore_probe(const double* obj, const double* img, int n, const
   cm.solver = 1;
   const bool has_dist = model == RCC_DIST_PLUMB_BOB;
   if (!has_dist) for (int i = 0; i < 5; ++i) cm.k[i] = 0.0;
-  rccpnp::SerialPar par;
+  double wsl[rccpnp::PNP_WS];
+  rccpnp::SerialPar par{ wsl };
   double Rt[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, Tt[3] = { 0, 0, 0 };
   double H[9];
   int ok = rccpnp::find_homography(par, p, Rt, Tt, cm, has_dist, H);
