@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--dense-variant", type=int, default=-1)
     ap.add_argument("--ingest-variant", type=int, default=-1)
     ap.add_argument("--roofline-reps", type=int, default=5)
+    ap.add_argument("--pipeline", type=int, default=1, help="chunks of the detector's two-stream pipeline per step (1: single pass)")
     ap.add_argument("--fiducials", default="", help="BASELINE.json configs[4]-style run: GXxGY planar grid of square fiducials per frame, e.g. 6x4")
     ap.add_argument("--fisheye", action="store_true", help="BASELINE.json configs[3]-style run: fisheye model (use with --width 3840 --height 2160 --batch 256)")
     return ap.parse_args()
@@ -73,6 +74,7 @@ def main():
     cfg.device = local
     cfg.batch_capacity = a.batch
     det = api.Detector(cfg)
+    det.set_pipeline(a.pipeline)
     det.set_dense_variant(a.dense_variant)
     det.set_ingest_variant(a.ingest_variant)
     B = a.batch
@@ -118,7 +120,12 @@ def main():
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # per-stage times: one extra (untimed) step as a single pass on one stream -- in the pipelined step the stages of
+    # different chunks overlap, so they have no separate durations
+    prev = det.set_pipeline(1)
+    step()
     timings = det.last_timings()
+    det.set_pipeline(prev)
 
     out = None
     if rank == 0:
@@ -133,7 +140,7 @@ def main():
                        "frames_per_step_per_gpu": B,
                        "target": ("%dx%d square fiducials of 0.10 m per frame (build family36b), 4-point PnP per tag" % fid) if fid else "8x6 inner-corner checkerboard, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
                        "parallelism": "frame-sharded, 1 process per GPU, 1 all_gather of pose records per step"},
-            "targets_found_in_last_step": int(found), "targets_expected_per_step": int(world * B * (fid[0] * fid[1] if fid else 1)), "stage_ms_last_step": timings,
+            "targets_found_in_last_step": int(found), "targets_expected_per_step": int(world * B * (fid[0] * fid[1] if fid else 1)), "stage_ms_single_pass": timings, "pipeline_chunks": a.pipeline,
         }
 
     # ---- roofline of the threshold+corner pass (the kernel BASELINE.json's north_star names) and

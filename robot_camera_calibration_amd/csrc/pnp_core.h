@@ -308,6 +308,14 @@ struct SerialPar {
   RCC_HD int step() const { return 1; }
   RCC_HD double sum(double v) const { return v; }
   RCC_HD double max(double v) const { return v; }
+  // out[q] = sum over the solver's lanes of v[q], q < N (here: one lane)
+  template <int N> RCC_HD void reduce_store(const double* v, double* out) const { for (int q = 0; q < N; ++q) out[q] = v[q]; }
+  // full symmetric N x N matrix from its packed upper triangle (row-major: (0,0) (0,1) .. (0,N-1) (1,1) ..)
+  template <int N> RCC_HD void unpack_sym(const double* tri, double* A) const
+  {
+    for (int r = 0, k = 0; r < N; ++r)
+      for (int c = r; c < N; ++c, ++k) { A[r * N + c] = tri[k]; A[c * N + r] = tri[k]; }
+  }
 };
 #ifdef __HIPCC__
 struct WavePar {
@@ -316,15 +324,103 @@ struct WavePar {
   __device__ double* ws() const { return w; }
   __device__ int first() const { return lane; }
   __device__ int step() const { return 64; }
-  __device__ double sum(double v) const {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  __device__ double sum(double v) const
+  {
+    v = both<5>(v); v = both<4>(v); v = both<3>(v); v = both<2>(v); v = both<1>(v); v = both<0>(v);
     return v;
   }
   __device__ double max(double v) const {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
     return v;
+  }
+
+  // ---- N sums over the 64 lanes at once (N <= 64), by recursive halving: at the level of lane bit b the
+  // lanes with bit b clear keep the first half of the remaining quantities and the others the second half,
+  // each adding what its partner held of the half it keeps.  P-1 exchange+add steps for P = N rounded up to
+  // a power of two, instead of 6 N for one butterfly per quantity; the total of quantity q ends in lane
+  // q * (64 / P), which stores it.  Exchanges: v_permlane32_swap / v_permlane16_swap (gfx950) for lane bits
+  // 5 and 4, DPP row rotations with bank masks for bits 3 and 2, DPP quad permutes for bits 1 and 0.
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ double mk(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32)); }
+  static __device__ __forceinline__ unsigned lo32(double d) { return (unsigned)__builtin_bit_cast(unsigned long long, d); }
+  static __device__ __forceinline__ unsigned hi32(double d) { return (unsigned)(__builtin_bit_cast(unsigned long long, d) >> 32); }
+  template <int CTRL, int BANKS>
+  static __device__ __forceinline__ double dpp_merge(double old, double v)
+  {
+    return mk(__builtin_amdgcn_update_dpp(lo32(old), lo32(v), CTRL, 0xf, BANKS, false),
+              __builtin_amdgcn_update_dpp(hi32(old), hi32(v), CTRL, 0xf, BANKS, false));
+  }
+  // one halving step at lane bit B: returns, in lanes with bit B clear, a + partner's a; in the others b + partner's b
+  template <int B>
+  __device__ __forceinline__ double halve(double a, double b) const
+  {
+    if (B == 5) {
+      const u32x2_t l = __builtin_amdgcn_permlane32_swap(lo32(a), lo32(b), false, false);
+      const u32x2_t h = __builtin_amdgcn_permlane32_swap(hi32(a), hi32(b), false, false);
+      return mk(l.x, h.x) + mk(l.y, h.y);
+    } else if (B == 4) {
+      const u32x2_t l = __builtin_amdgcn_permlane16_swap(lo32(a), lo32(b), false, false);
+      const u32x2_t h = __builtin_amdgcn_permlane16_swap(hi32(a), hi32(b), false, false);
+      return mk(l.x, h.x) + mk(l.y, h.y);
+    } else if (B == 3) {
+      const double recv = dpp_merge<0x128, 0x3>(dpp_merge<0x128, 0xC>(0.0, b), a);      // row_ror:8
+      return ((lane & 8) ? b : a) + recv;
+    } else if (B == 2) {
+      const double recv = dpp_merge<0x12C, 0x5>(dpp_merge<0x124, 0xA>(0.0, b), a);      // row_ror:12 / row_ror:4
+      return ((lane & 4) ? b : a) + recv;
+    } else {
+      const bool up = (lane & (1 << B)) != 0;
+      const double send = up ? a : b, keep = up ? b : a;
+      const double recv = (B == 1) ? dpp_merge<0x4E, 0xF>(0.0, send) : dpp_merge<0xB1, 0xF>(0.0, send);   // quad_perm [2,3,0,1] / [1,0,3,2]
+      return keep + recv;
+    }
+  }
+  // plain exchange+add at lane bit B (both partners end with the same sum)
+  template <int B>
+  __device__ __forceinline__ double both(double a) const { return halve<B>(a, a); }
+
+  template <int P, int B>
+  __device__ __forceinline__ void level(double* v) const
+  {
+    // P quantities remain per lane; after this level P/2 (P >= 2), or the same one summed over bit B (P == 1)
+    if (P >= 2) {
+#pragma unroll
+      for (int j = 0; j < P / 2; ++j) v[j] = halve<B>(v[j], v[j + P / 2]);
+    } else {
+      v[0] = both<B>(v[0]);
+    }
+  }
+  template <int N>
+  __device__ __forceinline__ void reduce_store(const double* vin, double* out) const
+  {
+    constexpr int P = N > 32 ? 64 : N > 16 ? 32 : N > 8 ? 16 : N > 4 ? 8 : N > 2 ? 4 : N > 1 ? 2 : 1;
+    double v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) v[q] = q < N ? vin[q] : 0.0;
+    level<P, 5>(v);
+    level<(P >= 2 ? P / 2 : 1), 4>(v);
+    level<(P >= 4 ? P / 4 : 1), 3>(v);
+    level<(P >= 8 ? P / 8 : 1), 2>(v);
+    level<(P >= 16 ? P / 16 : 1), 1>(v);
+    level<(P >= 32 ? P / 32 : 1), 0>(v);
+    // quantity q is complete in lanes q * (64/P) .. (q+1) * (64/P) - 1; the first of them stores it
+    constexpr int G = 64 / P;
+    const int q = lane / G;
+    if ((lane % G) == 0 && q < N) out[q] = v[0];
+  }
+  template <int N>
+  __device__ __forceinline__ void unpack_sym(const double* tri, double* A) const
+  {
+#pragma unroll
+    for (int base = 0; base < N * N; base += 64) {
+      const int l = base + lane;
+      if (l < N * N) {
+        const int r = l / N, c = l - r * N;
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        A[l] = tri[a * N - (a * (a - 1)) / 2 + (b - a)];
+      }
+    }
   }
 };
 #endif
@@ -521,14 +617,11 @@ template <class Par>
 RCC_HD inline double homography_accumulate(const Par& par, const double* h, const Pts& p, const double* Rt, const double* Tt,
                                            const Cam& cm, bool has_dist, double* A, double* v, double* rinf)
 {
-  double al[36], vl[8];                       // this lane's share of JtJ (upper triangle, row-major) and Jtr
-  if (A) {
+  // q[0..35]: this lane's share of JtJ (upper triangle, row-major), q[36..43]: of Jtr, q[44]: of S
+  double q[45];
 #pragma unroll
-    for (int i = 0; i < 36; ++i) al[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vl[i] = 0.0;
-  }
-  double S = 0.0, ri = 0.0;
+  for (int i = 0; i < 45; ++i) q[i] = 0.0;
+  double ri = 0.0;
   for (int i = par.first(); i < p.n; i += par.step()) {
     float Mxf, Myf, mxf, myf;
     plane_point(p, i, Rt, Tt, Mxf, Myf);
@@ -539,8 +632,8 @@ RCC_HD inline double homography_accumulate(const Par& par, const double* h, cons
     double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
     double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
     double e0 = xi - (double)mxf, e1 = yi - (double)myf;
-    S += e0 * e0;
-    S += e1 * e1;
+    q[44] += e0 * e0;
+    q[44] += e1 * e1;
     if (fabs(e0) > ri) ri = fabs(e0);
     if (fabs(e1) > ri) ri = fabs(e1);
     if (A) {
@@ -549,22 +642,22 @@ RCC_HD inline double homography_accumulate(const Par& par, const double* h, cons
 #pragma unroll
       for (int r = 0, k = 0; r < 8; ++r) {
 #pragma unroll
-        for (int c = r; c < 8; ++c, ++k) al[k] += a[r] * a[c] + b[r] * b[c];
-        vl[r] += a[r] * e0 + b[r] * e1;
+        for (int c = r; c < 8; ++c, ++k) q[k] += a[r] * a[c] + b[r] * b[c];
+        q[36 + r] += a[r] * e0 + b[r] * e1;
       }
     }
   }
-  S = par.sum(S);
   if (rinf) *rinf = par.max(ri);
+  double* const red = par.ws() + 192;         // 45 totals
   if (A) {
+    par.template reduce_store<45>(q, red);
+    par.template unpack_sym<8>(red, A);
 #pragma unroll
-    for (int r = 0, k = 0; r < 8; ++r) {
-#pragma unroll
-      for (int c = r; c < 8; ++c, ++k) { const double t = par.sum(al[k]); A[r * 8 + c] = t; A[c * 8 + r] = t; }
-      v[r] = par.sum(vl[r]);
-    }
+    for (int r = 0; r < 8; ++r) v[r] = red[36 + r];
+    return red[44];
   }
-  return S;
+  par.template reduce_store<1>(q + 44, red + 44);      // the same pairing tree as above: identical rounding
+  return red[44];
 }
 
 // A.4, N > 4: the LMSolver refinement used by findHomography(method 0), <= 10 iterations
@@ -658,24 +751,27 @@ template <class Par>
 RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const double* Rt, const double* Tt, const Cam& cm, bool has_dist, double H[9])
 {
   const int n = p.n;
-  double cMx = 0, cMy = 0, cmx = 0, cmy = 0;
+  double* const red4 = par.ws() + 192;
+  double c4[4] = { 0, 0, 0, 0 };
   for (int i = par.first(); i < n; i += par.step()) {
     float Mx, My, mx, my;
     plane_point(p, i, Rt, Tt, Mx, My);
     norm_point(p, i, cm, has_dist, mx, my);
-    cMx += Mx; cMy += My; cmx += mx; cmy += my;
+    c4[0] += Mx; c4[1] += My; c4[2] += mx; c4[3] += my;
   }
-  cMx = par.sum(cMx); cMy = par.sum(cMy); cmx = par.sum(cmx); cmy = par.sum(cmy);
+  par.template reduce_store<4>(c4, red4);
+  double cMx = red4[0], cMy = red4[1], cmx = red4[2], cmy = red4[3];
   cMx /= n; cMy /= n; cmx /= n; cmy /= n;
-  double sMx = 0, sMy = 0, smx = 0, smy = 0;
+  double s4[4] = { 0, 0, 0, 0 };
   for (int i = par.first(); i < n; i += par.step()) {
     float Mx, My, mx, my;
     plane_point(p, i, Rt, Tt, Mx, My);
     norm_point(p, i, cm, has_dist, mx, my);
-    sMx += fabs(Mx - cMx); sMy += fabs(My - cMy);
-    smx += fabs(mx - cmx); smy += fabs(my - cmy);
+    s4[0] += fabs(Mx - cMx); s4[1] += fabs(My - cMy);
+    s4[2] += fabs(mx - cmx); s4[3] += fabs(my - cmy);
   }
-  sMx = par.sum(sMx); sMy = par.sum(sMy); smx = par.sum(smx); smy = par.sum(smy);
+  par.template reduce_store<4>(s4, red4 + 4);
+  double sMx = red4[4], sMy = red4[5], smx = red4[6], smy = red4[7];
   if (fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON || fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON) return 0;
   smx = n / smx; smy = n / smy; sMx = n / sMx; sMy = n / sMy;
   double invHnorm[9] = { 1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1 };
@@ -697,10 +793,8 @@ RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const dou
 #pragma unroll
       for (int k = j; k < 9; ++k, ++q) ll[q] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
   }
-#pragma unroll
-  for (int j = 0, q = 0; j < 9; ++j)
-#pragma unroll
-    for (int k = j; k < 9; ++k, ++q) { const double t = par.sum(ll[q]); LtL[j * 9 + k] = t; LtL[k * 9 + j] = t; }
+  par.template reduce_store<45>(ll, par.ws() + 192);
+  par.template unpack_sym<9>(par.ws() + 192, LtL);
   double H0[9], T[9];
   if (!(cm.solver == 1 && smallest_eigvec_psd<9>(LtL, H0, par.ws() + 81))) {
     double* const L2 = LtL;                           // full decomposition (as published / fallback), in place
@@ -728,39 +822,35 @@ RCC_HD inline double pose_accumulate(const Par& par, const double* prm, const Pt
 {
   double R[9], dRdr[27];
   rodrigues_v2m(prm, R, A ? dRdr : nullptr);
-  double al[21], gl[6];                       // this lane's share of JtJ (upper triangle, row-major) and Jte
-  if (A) {
+  // q[0..20]: this lane's share of JtJ (upper triangle, row-major), q[21..26]: of Jte, q[27]: of S
+  double q[28];
 #pragma unroll
-    for (int i = 0; i < 21; ++i) al[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gl[i] = 0.0;
-  }
-  double S = 0.0;
+  for (int i = 0; i < 28; ++i) q[i] = 0.0;
   for (int i = par.first(); i < p.n; i += par.step()) {
     double uv[2], Ju[6], Jv[6];
     project_point(p.obj + 3 * i, R, dRdr, prm + 3, cm, uv, A ? Ju : nullptr, Jv);
     double e0 = uv[0] - p.img[2 * i], e1 = uv[1] - p.img[2 * i + 1];
-    S += e0 * e0;
-    S += e1 * e1;
+    q[27] += e0 * e0;
+    q[27] += e1 * e1;
     if (A) {
 #pragma unroll
       for (int a = 0, k = 0; a < 6; ++a) {
 #pragma unroll
-        for (int b = a; b < 6; ++b, ++k) al[k] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
-        gl[a] += Ju[a] * e0 + Jv[a] * e1;
+        for (int b = a; b < 6; ++b, ++k) q[k] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+        q[21 + a] += Ju[a] * e0 + Jv[a] * e1;
       }
     }
   }
-  S = par.sum(S);
+  double* const red = par.ws() + 192;         // 28 totals
   if (A) {
+    par.template reduce_store<28>(q, red);
+    par.template unpack_sym<6>(red, A);
 #pragma unroll
-    for (int a = 0, k = 0; a < 6; ++a) {
-#pragma unroll
-      for (int b = a; b < 6; ++b, ++k) { const double t = par.sum(al[k]); A[a * 6 + b] = t; A[b * 6 + a] = t; }
-      g[a] = par.sum(gl[a]);
-    }
+    for (int a = 0; a < 6; ++a) g[a] = red[21 + a];
+    return red[27];
   }
-  return S;
+  par.template reduce_store<1>(q + 27, red + 27);      // the same pairing tree as above: identical rounding
+  return red[27];
 }
 
 // A.1, A.3, A.5: the initial pose.  Returns a PNP_* status; prm = (r, t).

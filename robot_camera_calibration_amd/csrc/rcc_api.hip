@@ -121,6 +121,8 @@ void rcc_destroy(rcc_handle* h)
   if (h->h_ndet) (void)hipHostFree(h->h_ndet);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (auto& ps : h->pstream) if (ps) (void)hipStreamDestroy(ps);
+  for (auto& e : h->pev) if (e) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -139,6 +141,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->device = cfg->device;
   h->undist = cfg->undistort && cfg->dist_model != RCC_DIST_NONE;
   h->dense_variant = -1;
+  h->pipeline_chunks = 1;   // measured: chunking the batch over two streams is slower at every chunk count
   h->ingest_variant = -1;
   h->dense_skip = 1;
   h->pnp_variant = -1;
@@ -161,6 +164,8 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   if (hipSetDevice(h->device) != hipSuccess) { delete h; return RCC_ERR_DEVICE; }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RCC_ERR_DEVICE; }
   for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
+  for (auto& ps : h->pstream) if (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
+  for (auto& e : h->pev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   ALLOC(h->d_grey, B * px);
   ALLOC(h->d_bin, B * px);
   ALLOC(h->d_cand, B * (size_t)cfg->max_candidates * sizeof(rcc_cand));
@@ -298,39 +303,72 @@ int rcc_time_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* 
 }
 
 // list + subpix + validate/grid + pnp, then results to the host.  Events: ev[2]..ev[5].
-static int run_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, const rcc_cand* d_cand,
-                       const int32_t* d_cand_count, int nframes, rcc_detection* det, int32_t* ndet,
-                       rcc_frame_corners* corners, hipStream_t s)
+// list -> sub-pixel -> target identification -> pose, for the frames the (possibly offset) handle view covers
+static int launch_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, const rcc_cand* d_cand,
+                          const int32_t* d_cand_count, int nframes, hipStream_t s, bool timed)
 {
   const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
-  const int slots = h->cfg.max_targets;
-  HIPCHK(h, hipEventRecord(h->ev[2], s));
+  if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
   HIPCHK(h, rcc_launch_list(h, d_cand, d_cand_count, nframes, s));
   HIPCHK(h, rcc_launch_subpix(h, d_grey, nframes, s));
   if (fid) HIPCHK(h, rcc_launch_fid(h, d_grey, nframes, s));
   else HIPCHK(h, rcc_launch_grid(h, d_bin, nframes, s));
-  HIPCHK(h, hipEventRecord(h->ev[3], s));
+  if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
   if (fid) HIPCHK(h, rcc_launch_pnp_tags(h, nframes, s));
   else HIPCHK(h, rcc_launch_pnp_board(h, nframes, s));
-  HIPCHK(h, hipEventRecord(h->ev[4], s));
+  if (timed) HIPCHK(h, hipEventRecord(h->ev[4], s));
+  return RCC_OK;
+}
+
+// device -> host copy of the records, synchronise, compact into the caller's array
+static int collect_targets(rcc_handle* h, int nframes, rcc_detection* det, int32_t* ndet, rcc_frame_corners* corners,
+                           hipStream_t s, bool timed)
+{
+  const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
+  const int slots = h->cfg.max_targets;
   HIPCHK(h, hipMemcpyAsync(h->h_det, h->d_det, sizeof(rcc_detection) * (size_t)nframes * (fid ? slots : 1), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(h->h_ndet, h->d_ndet, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost, s));
   if (corners) HIPCHK(h, hipMemcpyAsync(corners, h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipEventRecord(h->ev[5], s));
+  if (timed) HIPCHK(h, hipEventRecord(h->ev[5], s));
   HIPCHK(h, hipStreamSynchronize(s));
   int n = 0;
   for (int f = 0; f < nframes; ++f) {
     const int k = h->h_ndet[f] < slots ? h->h_ndet[f] : slots;
     for (int q = 0; q < k; ++q) {
-      if (det) det[n] = h->h_det[(size_t)f * (fid ? slots : 1) + q];
+      if (det) { det[n] = h->h_det[(size_t)f * (fid ? slots : 1) + q]; det[n].frame = f; }   // batch index (kernels number within their chunk)
       ++n;
     }
   }
   if (ndet) *ndet = n;
-  (void)hipEventElapsedTime(&h->last_ms[2], h->ev[2], h->ev[3]);
-  (void)hipEventElapsedTime(&h->last_ms[3], h->ev[3], h->ev[4]);
-  (void)hipEventElapsedTime(&h->last_ms[4], h->ev[4], h->ev[5]);
+  if (timed) {
+    (void)hipEventElapsedTime(&h->last_ms[2], h->ev[2], h->ev[3]);
+    (void)hipEventElapsedTime(&h->last_ms[3], h->ev[3], h->ev[4]);
+    (void)hipEventElapsedTime(&h->last_ms[4], h->ev[4], h->ev[5]);
+  }
   return RCC_OK;
+}
+
+static int run_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, const rcc_cand* d_cand,
+                       const int32_t* d_cand_count, int nframes, rcc_detection* det, int32_t* ndet,
+                       rcc_frame_corners* corners, hipStream_t s)
+{
+  int r = launch_targets(h, d_grey, d_bin, d_cand, d_cand_count, nframes, s, true);
+  if (r != RCC_OK) return r;
+  return collect_targets(h, nframes, det, ndet, corners, s, true);
+}
+
+// a copy of the handle whose per-frame buffers start at frame f0: the launchers index frames from 0
+static rcc_handle handle_view(const rcc_handle* h, int f0)
+{
+  rcc_handle v = *h;
+  const size_t o = (size_t)f0, px = (size_t)h->cfg.width * h->cfg.height;
+  v.d_grey += o * px; v.d_bin += o * px;
+  v.d_cand += o * (size_t)h->cfg.max_candidates; v.d_cand_count += o;
+  v.d_pre += o * (size_t)h->kept_cap; v.d_npre += o; v.d_pre_xy += o * (size_t)h->kept_cap * 2;
+  v.d_kept += o * RCC_MAX_KEPT; v.d_kept_xy += o * RCC_MAX_KEPT * 2;
+  v.d_fc += o; v.d_det += o * (size_t)h->cfg.max_targets; v.d_ndet += o;
+  v.d_img_scratch += o * 2 * RCC_MAX_BOARD_CORNERS;
+  return v;
 }
 
 int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, const void* d_cand,
@@ -369,6 +407,35 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
     HIPCHK(h, hipMemcpyAsync(h->d_stage, frames, need, hipMemcpyHostToDevice, s));
     d_frames = h->d_stage;
   }
+  // Pipeline: the batch is cut into chunks that alternate over two streams, so that the latency-bound tail of
+  // one chunk (target identification and pose: one wavefront per frame, a single dependency chain each) runs
+  // under the bandwidth-bound head (ingest, threshold + corner pass) of the next.  Chunks only touch their own
+  // frames' slices of the handle's buffers.  Per-stage times are recorded only on the single-pass path.
+  int nchunks = h->pipeline_chunks;
+  if (nchunks > 1) {
+    const int min_chunk = 64;
+    if (nframes / nchunks < min_chunk) nchunks = nframes / min_chunk;
+  }
+  if (nchunks > 1) {
+    HIPCHK(h, hipEventRecord(h->pev[0], s));
+    for (int k = 0; k < 2; ++k) HIPCHK(h, hipStreamWaitEvent(h->pstream[k], h->pev[0], 0));
+    for (int c = 0; c < nchunks; ++c) {
+      const int f0 = (int)((long long)nframes * c / nchunks), f1 = (int)((long long)nframes * (c + 1) / nchunks);
+      rcc_handle v = handle_view(h, f0);
+      hipStream_t cs = h->pstream[c & 1];
+      hipError_t e = rcc_launch_ingest(&v, d_frames + (size_t)f0 * h->cfg.frame_bytes, f1 - f0, v.d_grey, cs);
+      if (e == hipSuccess) e = rcc_launch_dense(&v, v.d_grey, f1 - f0, v.d_bin, v.d_cand, v.d_cand_count, cs);
+      if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s", hipGetErrorString(e)); return RCC_ERR_DEVICE; }
+      int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, cs, false);
+      if (r != RCC_OK) { snprintf(h->err, sizeof(h->err), "%s", v.err); return r; }
+    }
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(h, hipEventRecord(h->pev[1 + k], h->pstream[k]));
+      HIPCHK(h, hipStreamWaitEvent(s, h->pev[1 + k], 0));
+    }
+    for (float& m : h->last_ms) m = -1.0f;
+    return collect_targets(h, nframes, det, ndet, corners, s, false);
+  }
   HIPCHK(h, hipEventRecord(h->ev[0], s));
   HIPCHK(h, rcc_launch_ingest(h, d_frames, nframes, h->d_grey, s));
   HIPCHK(h, hipEventRecord(h->ev[1], s));
@@ -378,6 +445,14 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
   (void)hipEventElapsedTime(&h->last_ms[0], h->ev[0], h->ev[1]);
   (void)hipEventElapsedTime(&h->last_ms[1], h->ev[1], h->ev[2]);
   return RCC_OK;
+}
+
+int rcc_set_pipeline(rcc_handle* h, int nchunks)
+{
+  if (!h || nchunks < 0 || nchunks > 64) return RCC_ERR_ARG;
+  int p = h->pipeline_chunks;
+  h->pipeline_chunks = nchunks;
+  return p;
 }
 
 // debug/parity taps: copy the handle's intermediate lists of the last batch to the host

@@ -57,6 +57,9 @@ struct rcc_handle {
   double* d_img_scratch;    // B x 256 x 2 image points handed to the solver
   hipEvent_t ev[8];
   float last_ms[5];
+  hipStream_t pstream[2];   // chunk streams of rcc_detect_batch's pipeline
+  hipEvent_t pev[3];        // [0] input ready on the caller's stream, [1..2] chunk streams drained
+  int pipeline_chunks;      // 0/1: one pass over the whole batch on one stream; n > 1: n chunks alternating over two streams
   int dense_variant, ingest_variant;
   int dense_skip;           // 1: the fast dense kernel may skip flat wave-rows (exact); 0: never (A/B, tests)
   int pnp_variant;          // -1 auto, 0 lane per target, 1 wavefront per target (board)

@@ -293,6 +293,24 @@ def test_kernel_variants_bit_identical(torch_cuda, oracle, pixfmt, w, h, n):
     det.close()
 
 
+def test_pipeline_chunks_identical(torch_cuda):
+    """rcc_set_pipeline: the chunked two-stream form of detect() returns the records of the single pass"""
+    torch = torch_cuda
+    n = 200
+    cfg = _make(w=640, h=480, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch, det, cfg, n, seed=4242)
+    torch.cuda.synchronize()
+    det.set_pipeline(1)
+    d1, f1 = det.detect(frames, n)
+    det.set_pipeline(3)
+    d3, f3 = det.detect(frames, n)
+    assert len(d1) == len(d3) > n // 2
+    assert d1.tobytes() == d3.tobytes()
+    assert f1.tobytes() == f3.tobytes()
+    det.close()
+
+
 def test_full_size_properties(torch_cuda):
     """1920x1080 (BASELINE.json's size), no oracle: size-independent properties of the path --
     idempotence (same frames twice -> identical records), batch-order independence (a frame's
