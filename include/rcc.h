@@ -248,6 +248,11 @@ int rcc_debug_fetch_lists(rcc_handle* h, int32_t nframes, void* pre, int32_t* np
 int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin, void* cand,
                            int32_t* cand_count);
 
+/* measurement aid: mean milliseconds of `reps` plain streaming copies (16 B per lane) of nbytes between two device
+ * buffers (16-byte aligned, nbytes a multiple of 16), timed with HIP events on the handle's stream.  bench.py
+ * quotes it beside the threshold+corner pass, which moves the same bytes. */
+int rcc_time_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes, int32_t reps, float* mean_ms);
+
 /* profiling aid: streaming copy with the dense pass's access width (4 B per lane), device pointers */
 int rcc_debug_calib_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes);
 /* test tap: intermediates of one PnP solve (host pointers), out[59] */

@@ -1,7 +1,7 @@
 // dense_rows.h -- the per-lane row pipeline of the threshold + corner pass (a3 + a4.1), shared by the two
 // row-marching kernels (k_dense_fast.hip: one wave per strip, registers only; k_dense_band.hip: one workgroup
 // per full-width band, grey rows staged through LDS).  Definitions: DESIGN.md section 3; bit-exact with
-// k_dense_lds (k_dense.hip) and with oracle/orc_image.c.
+// k_dense_lds (k_dense.hip) and with the CPU restatement the tests check against.
 //
 // Lane layout: a wavefront covers a 256-pixel window, lane l holds the 4 pixels x0 .. x0+3 (one dword of the
 // grey row); lanes 0, 1 and 63 are halo (the left lattice neighbour of the first useful pixel needs 5 pixels),

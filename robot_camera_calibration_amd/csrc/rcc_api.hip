@@ -492,6 +492,25 @@ int rcc_debug_calib_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t 
   return RCC_OK;
 }
 
+// measurement aid: mean time of a plain 16 B/lane streaming copy of nbytes (device pointers), the yardstick the
+// bandwidth-bound passes are compared with on the same box (bench.py's roofline leg)
+int rcc_time_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes, int32_t reps, float* mean_ms)
+{
+  if (!h || !d_src || !d_dst || nbytes < 16 || (nbytes & 15) || reps < 1 || !mean_ms) return RCC_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst)) & 15) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  HIPCHK(h, rcc_launch_copy_x4(d_src, d_dst, (size_t)nbytes, s));
+  HIPCHK(h, hipEventRecord(h->ev[6], s));
+  for (int r = 0; r < reps; ++r) HIPCHK(h, rcc_launch_copy_x4(d_src, d_dst, (size_t)nbytes, s));
+  HIPCHK(h, hipEventRecord(h->ev[7], s));
+  HIPCHK(h, hipEventSynchronize(h->ev[7]));
+  float ms = 0.0f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
+  *mean_ms = ms / (float)reps;
+  return RCC_OK;
+}
+
 // ---- solvePnP / Rodrigues drop-ins -----------------------------------------------------------------
 static int ensure_pnp_buf(rcc_handle* h, size_t bytes)
 {

@@ -88,6 +88,7 @@ hipError_t rcc_launch_pnp_generic(rcc_handle* h, const double* d_obj, const doub
                                   int32_t* d_status, int32_t* d_iters, hipStream_t s);
 hipError_t rcc_launch_pnp_probe(const double* d_obj, const double* d_img, int n, rcc_cam cam, double* d_out, hipStream_t s);
 hipError_t rcc_launch_calib_copy(const void* src, void* dst, size_t nbytes, hipStream_t s);
+hipError_t rcc_launch_copy_x4(const void* src, void* dst, size_t nbytes, hipStream_t s);
 hipError_t rcc_launch_rodrigues(int dir, const double* d_in, int n, double* d_out, hipStream_t s);
 hipError_t rcc_launch_synth(rcc_handle* h, const rcc_synth_params* sp, const double* d_poses,
                             int nframes, int first_index, uint8_t* d_frames, hipStream_t s);

@@ -18,6 +18,7 @@ for s0 in range(0, B, 64):
 px = 1920 * 1080
 grey = torch.empty((B, px), dtype=torch.uint8, device="cuda:0"); binm = torch.empty_like(grey)
 cand = torch.empty((B, cfg.max_candidates * 8), dtype=torch.uint8, device="cuda:0"); cnt = torch.empty((B,), dtype=torch.int32, device="cuda:0")
+torch.cuda.synchronize()
 det.stage_ingest(frames, B, grey)
 for _ in range(3):
     det.stage_threshold_corner(grey, B, binm, cand, cnt)
