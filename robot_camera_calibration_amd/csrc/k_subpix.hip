@@ -5,21 +5,15 @@
 // (real_preprocessing/src/corner_detections.cpp:53-54, where it casts them to int).
 //
 // Numerics: binary64 throughout; the five window sums are accumulated
-// one bin per lane (bin = sample index mod 64, increasing index) and combined by an xor-butterfly
-// v += shfl_xor(v, off), off = 32..1.  IEEE addition is commutative, so every lane ends with the
-// same value and the result equals the specification's 64-bin pairwise tree bit for bit.
+// one bin per lane (bin = sample index mod 64, increasing index) and combined along the xor-butterfly's
+// pairing tree (partners l ^ 32, then l ^ 16, .. l ^ 1; own + partner's).  IEEE addition is commutative,
+// so the result equals the specification's 64-bin pairwise tree bit for bit.
 // Compiled with -ffp-contract=off: every operation below is one rounded IEEE operation.
 #include "rcc_internal.h"
+#include "wave_reduce.h"
 
 #define SP_MAXW 7
 #define SP_MAXP (2 * SP_MAXW + 3)
-
-__device__ __forceinline__ double wave_tree_sum(double v)
-{
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
-  return v;
-}
 
 // grid (ceil(max_kept), nframes): block b handles candidate blockIdx.x of frame blockIdx.y
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
@@ -82,10 +76,15 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
       double v1 = gxy * px, v2 = gyy * py;
       b2 = b2 + (v1 + v2);
     }
-    a = wave_tree_sum(a);
-    b = wave_tree_sum(b);
-    c = wave_tree_sum(c);
-    double bb1 = wave_tree_sum(b1), bb2 = wave_tree_sum(b2);
+    // the five sums at once (wave_reduce.h): per quantity the pairing is the xor butterfly's (lane bit 5 first,
+    // bit 0 last; own + partner's, and IEEE addition commutes), so each total is the specification's 64-bin
+    // pairwise tree bit for bit; quantity q ends in lanes 8q..8q+7 and is broadcast through scalar registers
+    double red[8] = { a, b, c, b1, b2, 0.0, 0.0, 0.0 };
+    wred::reduce_scatter<8>(lane, red);
+    a = wred::bcast<0>(red[0]);
+    b = wred::bcast<8>(red[0]);
+    c = wred::bcast<16>(red[0]);
+    const double bb1 = wred::bcast<24>(red[0]), bb2 = wred::bcast<32>(red[0]);
     double ac = a * c, bsq = b * b;
     double det = ac - bsq;
     if (fabs(det) <= 2.2204460492503131e-16 * 2.2204460492503131e-16) break;

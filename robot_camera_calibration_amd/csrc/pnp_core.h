@@ -318,79 +318,24 @@ struct SerialPar {
   }
 };
 #ifdef __HIPCC__
+}  // namespace rccpnp
+#include "wave_reduce.h"
+namespace rccpnp {
 struct WavePar {
   int lane;
   double* w;
   __device__ double* ws() const { return w; }
   __device__ int first() const { return lane; }
   __device__ int step() const { return 64; }
-  __device__ double sum(double v) const
-  {
-    v = both<5>(v); v = both<4>(v); v = both<3>(v); v = both<2>(v); v = both<1>(v); v = both<0>(v);
-    return v;
-  }
+  __device__ double sum(double v) const { return wred::all_sum(lane, v); }
   __device__ double max(double v) const {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
     return v;
   }
 
-  // ---- N sums over the 64 lanes at once (N <= 64), by recursive halving: at the level of lane bit b the
-  // lanes with bit b clear keep the first half of the remaining quantities and the others the second half,
-  // each adding what its partner held of the half it keeps.  P-1 exchange+add steps for P = N rounded up to
-  // a power of two, instead of 6 N for one butterfly per quantity; the total of quantity q ends in lane
-  // q * (64 / P), which stores it.  Exchanges: v_permlane32_swap / v_permlane16_swap (gfx950) for lane bits
-  // 5 and 4, DPP row rotations with bank masks for bits 3 and 2, DPP quad permutes for bits 1 and 0.
-  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-  static __device__ __forceinline__ double mk(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32)); }
-  static __device__ __forceinline__ unsigned lo32(double d) { return (unsigned)__builtin_bit_cast(unsigned long long, d); }
-  static __device__ __forceinline__ unsigned hi32(double d) { return (unsigned)(__builtin_bit_cast(unsigned long long, d) >> 32); }
-  template <int CTRL, int BANKS>
-  static __device__ __forceinline__ double dpp_merge(double old, double v)
-  {
-    return mk(__builtin_amdgcn_update_dpp(lo32(old), lo32(v), CTRL, 0xf, BANKS, false),
-              __builtin_amdgcn_update_dpp(hi32(old), hi32(v), CTRL, 0xf, BANKS, false));
-  }
-  // one halving step at lane bit B: returns, in lanes with bit B clear, a + partner's a; in the others b + partner's b
-  template <int B>
-  __device__ __forceinline__ double halve(double a, double b) const
-  {
-    if (B == 5) {
-      const u32x2_t l = __builtin_amdgcn_permlane32_swap(lo32(a), lo32(b), false, false);
-      const u32x2_t h = __builtin_amdgcn_permlane32_swap(hi32(a), hi32(b), false, false);
-      return mk(l.x, h.x) + mk(l.y, h.y);
-    } else if (B == 4) {
-      const u32x2_t l = __builtin_amdgcn_permlane16_swap(lo32(a), lo32(b), false, false);
-      const u32x2_t h = __builtin_amdgcn_permlane16_swap(hi32(a), hi32(b), false, false);
-      return mk(l.x, h.x) + mk(l.y, h.y);
-    } else if (B == 3) {
-      const double recv = dpp_merge<0x128, 0x3>(dpp_merge<0x128, 0xC>(0.0, b), a);      // row_ror:8
-      return ((lane & 8) ? b : a) + recv;
-    } else if (B == 2) {
-      const double recv = dpp_merge<0x12C, 0x5>(dpp_merge<0x124, 0xA>(0.0, b), a);      // row_ror:12 / row_ror:4
-      return ((lane & 4) ? b : a) + recv;
-    } else {
-      const bool up = (lane & (1 << B)) != 0;
-      const double send = up ? a : b, keep = up ? b : a;
-      const double recv = (B == 1) ? dpp_merge<0x4E, 0xF>(0.0, send) : dpp_merge<0xB1, 0xF>(0.0, send);   // quad_perm [2,3,0,1] / [1,0,3,2]
-      return keep + recv;
-    }
-  }
-  // plain exchange+add at lane bit B (both partners end with the same sum)
-  template <int B>
-  __device__ __forceinline__ double both(double a) const { return halve<B>(a, a); }
-
-  template <int P, int B>
-  __device__ __forceinline__ void level(double* v) const
-  {
-    // P quantities remain per lane; after this level P/2 (P >= 2), or the same one summed over bit B (P == 1)
-    if (P >= 2) {
-#pragma unroll
-      for (int j = 0; j < P / 2; ++j) v[j] = halve<B>(v[j], v[j + P / 2]);
-    } else {
-      v[0] = both<B>(v[0]);
-    }
-  }
+  // N sums over the 64 lanes at once (N <= 64), by recursive halving (wave_reduce.h); the total of quantity q
+  // ends in lane q * (64 / P), which stores it
   template <int N>
   __device__ __forceinline__ void reduce_store(const double* vin, double* out) const
   {
@@ -398,13 +343,7 @@ struct WavePar {
     double v[P];
 #pragma unroll
     for (int q = 0; q < P; ++q) v[q] = q < N ? vin[q] : 0.0;
-    level<P, 5>(v);
-    level<(P >= 2 ? P / 2 : 1), 4>(v);
-    level<(P >= 4 ? P / 4 : 1), 3>(v);
-    level<(P >= 8 ? P / 8 : 1), 2>(v);
-    level<(P >= 16 ? P / 16 : 1), 1>(v);
-    level<(P >= 32 ? P / 32 : 1), 0>(v);
-    // quantity q is complete in lanes q * (64/P) .. (q+1) * (64/P) - 1; the first of them stores it
+    wred::reduce_scatter<P>(lane, v);
     constexpr int G = 64 / P;
     const int q = lane / G;
     if ((lane % G) == 0 && q < N) out[q] = v[0];
