@@ -29,6 +29,27 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   const int win = sp.win;
   const int ww = 2 * win + 1, pw = 2 * win + 3;
   const double x0 = (double)c0.x, y0 = (double)c0.y;
+  // per-lane sample tables (the window geometry does not change between iterations): patch samples
+  // idx = lane + 64 t < pw^2 and gradient samples k = lane + 64 t < ww^2 -- no integer division in the loop
+  constexpr int PT = (SP_MAXP * SP_MAXP + 63) / 64, GT = ((2 * SP_MAXW + 1) * (2 * SP_MAXW + 1) + 63) / 64;
+  int poff[PT];            // (i - win - 1) * w + (j - win - 1): offset of the sample's top-left tap from (iy, ix)
+  int goff[GT];            // (i + 1) * pw + (j + 1): centre of the gradient stencil in S
+  double gm[GT], gpx[GT], gpy[GT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int idx = lane + 64 * t;
+    const int i = idx / pw, j = idx - i * pw;
+    poff[t] = (i - win - 1) * w + (j - win - 1);
+  }
+#pragma unroll
+  for (int t = 0; t < GT; ++t) {
+    const int k = lane + 64 * t;
+    const int i = k / ww, j = k - i * ww;
+    goff[t] = (i + 1) * pw + (j + 1);
+    const bool ok = k < ww * ww;
+    gm[t] = ok ? sp.m1[i] * sp.m1[j] : 0.0;
+    gpx[t] = (double)(j - win); gpy[t] = (double)(i - win);
+  }
   double cx = x0, cy = y0;
   int iter = 0;
   bool bad = false;
@@ -44,37 +65,44 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
     double ofx = 1.0 - fx, ofy = 1.0 - fy;
     double a00 = ofx * ofy, a01 = fx * ofy, a10 = ofx * fy, a11 = fx * fy;
     __syncthreads();   // previous iteration's readers are done with S
-    for (int idx = lane; idx < pw * pw; idx += 64) {
-      int i = idx / pw, j = idx - i * pw;
-      const uint8_t* p = g + (size_t)(iy + i - win - 1) * w + (ix + j - win - 1);
-      double t0 = a00 * (double)p[0];
-      double t1 = a01 * (double)p[1];
-      double t2 = a10 * (double)p[w];
-      double t3 = a11 * (double)p[w + 1];
-      double s = t0 + t1;
-      s = s + t2;
-      s = s + t3;
-      S[idx] = s;
+    const uint8_t* pc = g + (size_t)iy * w + ix;
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int idx = lane + 64 * t;
+      if (idx < pw * pw) {
+        const uint8_t* p = pc + poff[t];
+        double t0 = a00 * (double)p[0];
+        double t1 = a01 * (double)p[1];
+        double t2 = a10 * (double)p[w];
+        double t3 = a11 * (double)p[w + 1];
+        double s = t0 + t1;
+        s = s + t2;
+        s = s + t3;
+        S[idx] = s;
+      }
     }
     __syncthreads();
     double a = 0.0, b = 0.0, c = 0.0, b1 = 0.0, b2 = 0.0;
-    for (int k = lane; k < ww * ww; k += 64) {
-      int i = k / ww, j = k - i * ww;
-      const double* spp = S + (i + 1) * pw + (j + 1);
-      double gx = spp[1] - spp[-1];
-      double gy = spp[pw] - spp[-pw];
-      double m = sp.m1[i] * sp.m1[j];
-      double gxx = (gx * gx) * m;
-      double gxy = (gx * gy) * m;
-      double gyy = (gy * gy) * m;
-      double px = (double)(j - win), py = (double)(i - win);
-      a = a + gxx;
-      b = b + gxy;
-      c = c + gyy;
-      double u1 = gxx * px, u2 = gxy * py;
-      b1 = b1 + (u1 + u2);
-      double v1 = gxy * px, v2 = gyy * py;
-      b2 = b2 + (v1 + v2);
+#pragma unroll
+    for (int t = 0; t < GT; ++t) {
+      const int k = lane + 64 * t;
+      if (k < ww * ww) {
+        const double* spp = S + goff[t];
+        double gx = spp[1] - spp[-1];
+        double gy = spp[pw] - spp[-pw];
+        double m = gm[t];
+        double gxx = (gx * gx) * m;
+        double gxy = (gx * gy) * m;
+        double gyy = (gy * gy) * m;
+        double px = gpx[t], py = gpy[t];
+        a = a + gxx;
+        b = b + gxy;
+        c = c + gyy;
+        double u1 = gxx * px, u2 = gxy * py;
+        b1 = b1 + (u1 + u2);
+        double v1 = gxy * px, v2 = gyy * py;
+        b2 = b2 + (v1 + v2);
+      }
     }
     // the five sums at once (wave_reduce.h): per quantity the pairing is the xor butterfly's (lane bit 5 first,
     // bit 0 last; own + partner's, and IEEE addition commutes), so each total is the specification's 64-bin
