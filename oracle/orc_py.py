@@ -27,7 +27,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liborc.so")
+        so = os.environ.get("ORC_LIBRARY") or os.path.join(_HERE, "liborc.so")   # ORC_LIBRARY: e.g. a sanitizer build
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)

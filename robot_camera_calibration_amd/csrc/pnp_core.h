@@ -191,9 +191,10 @@ RCC_HD inline void spd_solve(int solver, const double* A, const double* b, doubl
 #pragma unroll
       for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
       if (!(d > tiny)) ok = false;
-      const double dj = sqrt(d > tiny ? d : 1.0);
-      L[j * N + j] = dj;
-      const double idj = 1.0 / dj;
+      // the diagonal holds 1 / L_jj: the substitutions below multiply (an fp64 division or square root is a
+      // 10-20 instruction sequence on the solver's single dependency chain)
+      const double idj = 1.0 / sqrt(d > tiny ? d : 1.0);
+      L[j * N + j] = idj;
 #pragma unroll
       for (int i = j + 1; i < N; ++i) {
         double t = A[i * N + j];
@@ -219,14 +220,14 @@ RCC_HD inline void spd_solve(int solver, const double* A, const double* b, doubl
     double t = b[i];
 #pragma unroll
     for (int k = 0; k < i; ++k) t -= L[i * N + k] * y[k];
-    y[i] = t / L[i * N + i];
+    y[i] = t * L[i * N + i];
   }
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {       // L^T x = y
     double t = y[i];
 #pragma unroll
     for (int k = i + 1; k < N; ++k) t -= L[k * N + i] * x[k];
-    x[i] = t / L[i * N + i];
+    x[i] = t * L[i * N + i];
   }
 }
 
@@ -252,9 +253,8 @@ RCC_HD inline int smallest_eigvec_psd(const double* M, double* x /* N */, double
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
     if (!(d > 0.0)) ok = false;
-    const double dj = sqrt(d > 0.0 ? d : 1.0);
-    L[j * N + j] = dj;
-    const double idj = 1.0 / dj;
+    const double idj = 1.0 / sqrt(d > 0.0 ? d : 1.0);
+    L[j * N + j] = idj;                       // the diagonal holds 1 / L_jj (see spd_solve)
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
       double t = M[i * N + j];
@@ -273,14 +273,14 @@ RCC_HD inline int smallest_eigvec_psd(const double* M, double* x /* N */, double
       double t = x[i];
 #pragma unroll
       for (int k = 0; k < i; ++k) t -= L[i * N + k] * x[k];
-      x[i] = t / L[i * N + i];
+      x[i] = t * L[i * N + i];
     }
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
       double t = x[i];
 #pragma unroll
       for (int k = i + 1; k < N; ++k) t -= L[k * N + i] * x[k];
-      x[i] = t / L[i * N + i];
+      x[i] = t * L[i * N + i];
     }
     double nr = 0.0;
 #pragma unroll
@@ -300,7 +300,7 @@ RCC_HD inline int smallest_eigvec_psd(const double* M, double* x /* N */, double
 // factors).  One copy per solver instance: per thread for SerialPar, per wavefront (in LDS) for WavePar --
 // replicated in the registers of 64 lanes these matrices spill to scratch, and every spilled access costs a
 // memory round trip on the solver's single dependency chain.
-enum { PNP_WS = 256 };
+enum { PNP_WS = 320 };   // [0,192) matrices and factors, [192,256) reduction totals, [256,320) normalised points (<= 64)
 struct SerialPar {
   double* w;
   RCC_HD double* ws() const { return w; }
@@ -534,6 +534,7 @@ struct Pts {
   const double* obj;
   const double* img;
   int n;
+  const float* nm;   // optional: the n image points already through undistortPoints and rounded to float (pose_init fills it)
 };
 
 // in-plane coordinates (float32-rounded, as findHomography converts its inputs) of point i
@@ -545,6 +546,7 @@ RCC_HD inline void plane_point(const Pts& p, int i, const double* Rt, const doub
 }
 RCC_HD inline void norm_point(const Pts& p, int i, const Cam& cm, bool has_dist, float& mx, float& my)
 {
+  if (p.nm) { mx = p.nm[2 * i]; my = p.nm[2 * i + 1]; return; }
   double x, y;
   undistort_point(cm, has_dist, p.img[2 * i], p.img[2 * i + 1], x, y);
   mx = (float)x; my = (float)y;
@@ -681,6 +683,9 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
     for (int i = 0; i < P; ++i) if (fabs(d[i]) > dinf) dinf = fabs(d[i]);
     if (!(iter < maxIters && dinf >= epsx && rinf >= epsf)) break;
   }
+#ifdef RCC_PNP_TRACE_REFINE
+  RCC_PNP_TRACE_REFINE(iter);
+#endif
 #pragma unroll
   for (int i = 0; i < 8; ++i) h[i] = x[i];
 }
@@ -830,7 +835,14 @@ RCC_NI RCC_HD inline int pose_init(const Par& par, const Pts& p, const Cam& cm, 
   for (int a = 0; a < 3; ++a) Tt[a] = -(Rt[a * 3] * Mc[0] + Rt[a * 3 + 1] * Mc[1] + Rt[a * 3 + 2] * Mc[2]);
   double H[9], R[9], t[3], r[3];
   int status = PNP_OK;
-  if (find_homography(par, p, Rt, Tt, cm, has_dist, H)) {
+  // the homography stages visit every image point many times: normalise each once (5 fixed-point iterations)
+  Pts pc = p;
+  if (n <= 64 && !p.nm) {
+    float* nm = reinterpret_cast<float*>(par.ws() + 256);
+    for (int i = par.first(); i < n; i += par.step()) norm_point(p, i, cm, has_dist, nm[2 * i], nm[2 * i + 1]);
+    pc.nm = nm;
+  }
+  if (find_homography(par, pc, Rt, Tt, cm, has_dist, H)) {
     double h1[3] = { H[0], H[3], H[6] }, h2[3] = { H[1], H[4], H[7] };
     t[0] = H[2]; t[1] = H[5]; t[2] = H[8];
     double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
@@ -880,7 +892,10 @@ RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* r
     if (it == 0) prevErr = sqrt(S0);
     double errNorm;
     for (;;) {
-      double lambda = exp((double)L * log(10.0));
+      // 10^L, L in [-16, 17]: exact decimal constants instead of exp(L log 10) (two libm calls per trial step)
+      const double p10[34] = { 1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0,
+                               1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17 };
+      double lambda = p10[(L < -16 ? -16 : (L > 17 ? 17 : L)) + 16];
 #pragma unroll
       for (int i = 0; i < 36; ++i) Ap[i] = A[i];
 #pragma unroll
