@@ -57,17 +57,27 @@ __device__ bool fid_corner_class(const uint8_t* __restrict__ g, int w, int h, in
   return true;
 }
 
+// all 16 probes are loaded before any is tested: one memory latency instead of up to eight dependent ones
+// (the decision is unchanged: false if any probe leaves the image, else at least 7 of 8 two-sided probes good)
 __device__ bool fid_edge_ok(const uint8_t* __restrict__ g, int w, int h, int xi, int yi, int wx, int wy, int nx, int ny, int t)
 {
   const int ox = fid_rdiv10(nx), oy = fid_rdiv10(ny);
-  int good = 0;
+  bool inb = true;
+  int vb[8], vc[8];
+#pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int mx = (xi * 16 + wx * (2 * k + 1) + 8) >> 4, my = (yi * 16 + wy * (2 * k + 1) + 8) >> 4;
     const int bx = mx + ox, by = my + oy, cx = mx - ox, cy = my - oy;
-    if (bx < 0 || by < 0 || bx >= w || by >= h || cx < 0 || cy < 0 || cx >= w || cy >= h) return false;
-    if (g[(size_t)by * w + bx] <= t && g[(size_t)cy * w + cx] > t) ++good;
+    const bool ok = !(bx < 0 || by < 0 || bx >= w || by >= h || cx < 0 || cy < 0 || cx >= w || cy >= h);
+    inb = inb && ok;
+    const int bxc = min(max(bx, 0), w - 1), byc = min(max(by, 0), h - 1), cxc = min(max(cx, 0), w - 1), cyc = min(max(cy, 0), h - 1);
+    vb[k] = g[(size_t)byc * w + bxc];
+    vc[k] = g[(size_t)cyc * w + cxc];
   }
-  return good >= 7;
+  int good = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) good += (vb[k] <= t && vc[k] > t) ? 1 : 0;
+  return inb && good >= 7;
 }
 
 __device__ bool fid_homography(const double q[8], double H[9])
@@ -225,26 +235,65 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
   // phase 2: link along d1 (black on the (-dy, dx) side of the direction of travel): nearest accepted
   for (int i = tid; i < n; i += 256) s_nxt[i] = -1;
   __syncthreads();
-  for (int ci = tid; ci < nc; ci += 256) {
-    const int i = s_cidx[ci];
-    int best = -1;
+  // The specification: among the corners j that pass the integer gates (distance, direction, cone) AND whose
+  // connecting segment verifies (fid_edge_ok), the nearest one, ties to the smallest index.  The verification
+  // reads 16 pixels; done inside the scan it ran whenever any lane of the wave had a candidate (a few memory
+  // latencies per scan step: 4 ms per batch).  So: (A) a pure-ALU scan keeps the FK nearest gate-passers in
+  // (distance, index) order; (B) they are verified in that order, all lanes in step; (C) only if all FK fail and
+  // more passed the gates, the plain scan finishes the job (rare; keeps the result exact).
+  constexpr int FK = 4;
+  for (int c0 = 0; c0 < nc; c0 += 256) {
+    const int ci = c0 + tid;
+    const bool act = ci < nc;
+    const int i = act ? s_cidx[ci] : 0;
     const int dx = s_dx[i], dy = s_dy[i], dd = dx * dx + dy * dy;
     const int xi = s_px[i], yi = s_py[i], t = s_thr[i];
-    int bestd = 0;
-    for (int cj = 0; cj < nc; ++cj) {
-      const int j = s_cidx[cj];
-      if (j == i) continue;
-      const int wx = s_px[j] - xi, wy = s_py[j] - yi;
-      const int ww = wx * wx + wy * wy;                    // <= 2 * 16384^2 fits int32
-      if (ww < 64) continue;
-      if (wx * dx + wy * dy <= 0) continue;
-      const long long cr = (long long)wx * dy - (long long)wy * dx;
-      if (8 * cr * cr > (long long)ww * dd) continue;
-      if (best >= 0 && ww >= bestd) continue;
-      if (!fid_edge_ok(g, w, h, xi, yi, wx, wy, -dy, dx, t)) continue;
-      best = j; bestd = ww;
+    int cj[FK], cw[FK], npass = 0;
+#pragma unroll
+    for (int q = 0; q < FK; ++q) { cj[q] = -1; cw[q] = 0x7FFFFFFF; }
+    if (act) {
+      for (int cjx = 0; cjx < nc; ++cjx) {
+        const int j = s_cidx[cjx];
+        const int wx = s_px[j] - xi, wy = s_py[j] - yi;
+        const int ww = wx * wx + wy * wy;                    // <= 2 * 16384^2 fits int32
+        const long long cr = (long long)wx * dy - (long long)wy * dx;
+        const bool pass = (j != i) && (ww >= 64) && (wx * dx + wy * dy > 0) && (8 * cr * cr <= (long long)ww * dd);
+        if (pass) {
+          ++npass;
+          // insert (ww, j) into the ascending list; j ascends along the scan, so an equal ww goes after its equals
+          int jw = ww, jj = j;
+#pragma unroll
+          for (int q = 0; q < FK; ++q) {
+            if (jw < cw[q]) { const int tw = cw[q], tj = cj[q]; cw[q] = jw; cj[q] = jj; jw = tw; jj = tj; }
+          }
+        }
+      }
     }
-    s_nxt[i] = (int16_t)best;
+    int best = -1;
+#pragma unroll
+    for (int q = 0; q < FK; ++q) {
+      if (act && best < 0 && cj[q] >= 0) {
+        const int j = cj[q];
+        if (fid_edge_ok(g, w, h, xi, yi, s_px[j] - xi, s_py[j] - yi, -dy, dx, t)) best = j;
+      }
+    }
+    if (act && best < 0 && npass > FK) {
+      int bestd = 0;
+      for (int cjx = 0; cjx < nc; ++cjx) {
+        const int j = s_cidx[cjx];
+        if (j == i) continue;
+        const int wx = s_px[j] - xi, wy = s_py[j] - yi;
+        const int ww = wx * wx + wy * wy;
+        if (ww < 64) continue;
+        if (wx * dx + wy * dy <= 0) continue;
+        const long long cr = (long long)wx * dy - (long long)wy * dx;
+        if (8 * cr * cr > (long long)ww * dd) continue;
+        if (best >= 0 && ww >= bestd) continue;
+        if (!fid_edge_ok(g, w, h, xi, yi, wx, wy, -dy, dx, t)) continue;
+        best = j; bestd = ww;
+      }
+    }
+    if (act) s_nxt[i] = (int16_t)best;
   }
   __syncthreads();
   // phase 3: 4-cycles from their smallest index, decode
