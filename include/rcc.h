@@ -213,6 +213,12 @@ int rcc_set_ingest_variant(rcc_handle* h, int variant);
 /* fast dense variant only: 1 (default) lets it skip the corner stages on wave-rows whose tiles are all
  * low-contrast (exact: see k_dense_fast.hip), 0 disables the skip.  Returns the previous value. */
 int rcc_set_dense_skip(rcc_handle* h, int on);
+/* rcc_detect_batch and the binary image: the stages after the threshold+corner pass read it at 16 ring points per
+ * corner only, so by default the pass leaves it as a compact map (one byte per 4x4 tile: level or "flat") -- 1/16 of
+ * the output bytes, same decisions -- and rcc_debug_fetch_images expands it on demand.  on = 1 makes
+ * rcc_detect_batch materialise the full binary image (as rcc_stage_threshold_corner always does).  Returns the
+ * previous setting. */
+int rcc_set_keep_binary(rcc_handle* h, int on);
 /* rcc_detect_batch pipeline: n > 1 cuts a batch into n chunks (at least 64 frames each) that alternate over two
  * internal streams, so that the per-frame dependency chains of target identification and pose run under the
  * bandwidth-bound passes of the next chunk; 0 or 1 = one pass on one stream (per-stage times of rcc_last_timings

@@ -214,6 +214,7 @@ hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, u
   if (variant < 0) variant = band_ok ? 1 : (march_ok ? 2 : 0);
   if (variant == 1 && !band_ok) variant = march_ok ? 2 : 0;
   if (variant == 2 && !march_ok) variant = 0;
+  h->bin_from_thr = 0;      // only the band kernel can leave the binary image as the compact threshold map
   if (variant == 1) return rcc_launch_dense_band(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s);
   if (variant == 2) return rcc_launch_dense_march(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s);
   const int w = c.width, ht = c.height;

@@ -21,16 +21,15 @@
 //   * threshold dwords go to an LDS row buffer; one iteration later wave j stores columns [256 j, 256 j + 256)
 //     of the four rows with one dwordx4 store (quarter-wave per row).
 // Synchronisation: one s_barrier per tile row.  Ring of 6 slots, DMA three tile rows ahead; the wait before the
-// barrier is a COUNTED s_waitcnt vmcnt(5): every wave issues exactly one DMA and one store per iteration (both
-// unconditional -- masked lanes / rows get an out-of-range buffer offset, which the hardware drops), so the DMA
-// of tile row t has exactly 5 younger operations when it is waited for.  (hipcc is kept out of this
+// barrier is a COUNTED s_waitcnt vmcnt(5): every wave issues at least one DMA and exactly one store per iteration
+// (both unconditional -- masked lanes / rows get an out-of-range buffer offset, which the hardware drops), so the
+// DMA of tile row t has at least 5 younger operations when it is waited for (the first three tile rows are
+// waited for outright in the prologue).  (hipcc is kept out of this
 // bookkeeping: the DMA is inline asm, since for the builtin it drains vmcnt(0) before every LDS read.)
 #include "dense_rows.h"
 
 #define BAND_WAVES 8
-#define BAND_W 1920
-#define BAND_NCH 9
-#define BAND_SLOT (BAND_NCH * 1024)
+#define BAND_W RCC_BAND_W
 #define BAND_RING 6
 #define BAND_DEPTH 3
 #define BAND_OPITCH 2048
@@ -51,15 +50,21 @@ __device__ __forceinline__ void dma_1k(i32x4 rsrc, unsigned lds_addr, int voff, 
                : "memory");
 }
 
-template <int MODE, int PRIO>   // MODE 0: the pass; 1: its data movement only (experiment).  PRIO: raise the priority of computing waves
-__global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ grey, int w, int h,
-                                                    int nbands, int nseg, int seg_tiles, int nframes,
-                                                    int min_contrast, int hthresh, int margin, int cap, int allow_skip,
-                                                    uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand,
-                                                    int32_t* __restrict__ cand_count)
+// MODE 0: the pass; 1: its data movement only (experiment); 2: the pass with the binary image left as the compact
+// threshold map (one byte per 4x4 tile: 255 = flat, else the level) -- what rcc_detect_batch needs, 1/16 of the
+// output bytes.  PRIO: raise the priority of computing waves.  NCH: 256-B chunks per staged row (8 when the frame
+// is one band of at most 2048 columns, else 9: the ring then fits three workgroups per CU).
+template <int MODE, int PRIO, int NCH>
+__device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey, int w, int h,
+                                                int nbands, int nseg, int seg_tiles, int nframes,
+                                                int min_contrast, int hthresh, int margin, int cap, int allow_skip,
+                                                uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand,
+                                                int32_t* __restrict__ cand_count)
 {
+  constexpr int BAND_SLOT = NCH * 1024;
+  constexpr bool THR = (MODE == 2);
   __shared__ __attribute__((aligned(1024))) uint8_t ring[BAND_RING * BAND_SLOT];
-  __shared__ __attribute__((aligned(16))) uint8_t obuf[2 * BAND_OBUF];
+  __shared__ __attribute__((aligned(16))) uint8_t obuf[THR ? 2 * RCC_THR_PITCH : 2 * BAND_OBUF];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int job = blockIdx.x;
@@ -76,7 +81,9 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
   const bool lane_out = (lane >= 2) && (lane <= 62) && (x0 >= X0) && (x0 < X1);
   const bool wave_on = (X0 + wv * STRIP_USE) < X1;             // wave-uniform: does this window hold band pixels?
   const uint8_t* gf = grey + (size_t)f * w * h;
-  uint8_t* bo = bin + (size_t)f * w * h;
+  // output: the frame's binary image, or (THR) this band's slice of the frame's compact threshold map
+  const int out_bytes = THR ? th * RCC_THR_PITCH : w * h;
+  uint8_t* bo = THR ? bin + ((size_t)f * nbands + band) * (size_t)th * RCC_THR_PITCH : bin + (size_t)f * w * h;
   if (margin < 6) margin = 6;
 
   // ---- addressing constants
@@ -86,14 +93,14 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
   rs_g.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(ga >> 32) & 0xFFFFu));
   rs_g.z = w * h;
   rs_g.w = 0x00020000;
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(bo, 0, w * h, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(bo, 0, out_bytes, 0x00020000);
   const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
   const int dk = lane >> 4, di = lane & 15;                    // quarter-wave k moves row k, 16 B per lane
   const int dma_col = XI0 + 256 * wv + 16 * di;                // this wave's chunk = wv (and 8 for wave 0)
-  const bool need_c8 = (wv == 0) && (min(w - 4, X0 + (BAND_WAVES - 1) * STRIP_USE - 8 + 252) - XI0 >= 2048);
+  const bool need_c8 = (NCH > 8) && (wv == 0) && (min(w - 4, X0 + (BAND_WAVES - 1) * STRIP_USE - 8 + 252) - XI0 >= 2048);
   const int rel = xl - XI0;
   const unsigned rd_off = (unsigned)((rel >> 8) * 1024 + (rel & 255));        // + 256 k + slot
-  const unsigned wr_off = (unsigned)(lane_out ? (x0 - X0) : 0);                // + BAND_OPITCH k + buffer
+  const unsigned wr_off = (unsigned)(lane_out ? (THR ? (x0 - X0) >> 2 : (x0 - X0)) : 0);   // + BAND_OPITCH k + buffer (THR: tile index)
   const int fl_col = X0 + 256 * wv + 16 * di;                  // flush: this lane's 16 output bytes of row dk
   const bool fl_ok = fl_col < X1;
   const unsigned fl_rd = (unsigned)(dk * BAND_OPITCH + 256 * wv + 16 * di);
@@ -106,11 +113,19 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
     dma_1k(rs_g, ring_lds + (unsigned)(slot * BAND_SLOT + wv * 1024), (int)__umul24((unsigned)rr, (unsigned)w) + dma_col, 0);
     if (need_c8) dma_1k(rs_g, ring_lds + (unsigned)(slot * BAND_SLOT + 8 * 1024), (int)__umul24((unsigned)rr, (unsigned)w) + dma_col + 2048, 0);
   };
-  // the four staged output rows of tile row tt (buffer tt & 1 ... written one iteration ago) -> global, whole lines
+  // the staged output of tile row tt (written one iteration ago) -> global, whole lines: four image rows of 256
+  // bytes per wave, or (THR) the band's 512-byte map row by waves 0 and 1.  Every wave issues the store (dropped
+  // through an out-of-range offset where it has nothing to write): the counted wait relies on it.
   auto flush = [&](int tt, int buf) {
     const bool ok = (tt >= t0) && (tt < t1);                   // scalar
-    const u32x4 q = *reinterpret_cast<const u32x4*>(obuf + buf * BAND_OBUF + fl_rd);
-    __builtin_amdgcn_raw_buffer_store_b128(q, rs_b, ok ? fl_voff : BAND_INVALID, __builtin_amdgcn_readfirstlane(ok ? 4 * tt * w : 0), 0);
+    if (THR) {
+      const unsigned q = *reinterpret_cast<const unsigned*>(obuf + buf * RCC_THR_PITCH + ((256 * wv + 4 * lane) & (RCC_THR_PITCH - 1)));
+      __builtin_amdgcn_raw_buffer_store_b32(q, rs_b, (ok && wv < 2) ? 256 * wv + 4 * lane : BAND_INVALID,
+                                            __builtin_amdgcn_readfirstlane(ok ? tt * RCC_THR_PITCH : 0), 0);
+    } else {
+      const u32x4 q = *reinterpret_cast<const u32x4*>(obuf + buf * BAND_OBUF + fl_rd);
+      __builtin_amdgcn_raw_buffer_store_b128(q, rs_b, ok ? fl_voff : BAND_INVALID, __builtin_amdgcn_readfirstlane(ok ? 4 * tt * w : 0), 0);
+    }
   };
   auto read_tile = [&](int slot) -> Tile4 {
     const uint8_t* p = ring + slot * BAND_SLOT + rd_off;
@@ -121,7 +136,11 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
     T.g3 = *reinterpret_cast<const unsigned*>(p + 768);
     return T;
   };
+  auto stage_thr = [&](int buf, int level) {     // THR: one byte per lane = its tile of this tile row
+    if (lane_out) obuf[buf * RCC_THR_PITCH + wr_off] = (uint8_t)level;
+  };
   auto stage_out = [&](int buf, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+    if (THR) return;
     if (lane_out) {
       uint8_t* p = obuf + buf * BAND_OBUF + wr_off;
       *reinterpret_cast<unsigned*>(p) = v0;
@@ -165,12 +184,15 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
       Fn = allow_skip ? (((t - 1) < t0 - 1) ? 1 : flatN) : 0;   // warm-up rows: "don't care" (strip kernel)
       // ---- BACK
       const int tau = t - 2;
+      if (THR) stage_thr(ob, flatB ? 255 : thrB);            // tile row tau's level (thrB <= 254 when not flat)
       if (tau >= t0 - 2) {
         if (__any(!(Fa && Fb && Fn))) {
           if (PRIO) __builtin_amdgcn_s_setprio(2);          // the wave on the critical path of this iteration
           const Tile4 B = read_tile(sb2);
-          const Thr4 thr(thrB, flatB);
-          stage_out(ob, thr(B.g0), thr(B.g1), thr(B.g2), thr(B.g3));
+          if (!THR) {
+            const Thr4 thr(thrB, flatB);
+            stage_out(ob, thr(B.g0), thr(B.g1), thr(B.g2), thr(B.g3));
+          }
           P.row(4 * tau + 0, 0, B.g0, sa, sb, sc, 0);
           P.row(4 * tau + 1, 1, B.g1, sb, sc, sa, Fa);     // produces lattice row 4*tau-2, in tile row tau-1
           P.row(4 * tau + 2, 2, B.g2, sc, sa, sb, 0);
@@ -187,14 +209,14 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
     sf = (sf + 1 == BAND_RING) ? 0 : sf + 1;
   };
 
-  // prologue: tile rows t0-2 .. t0 in flight, each followed by a (dropped) store so that the operation count per
-  // tile row is the loop's
+  // prologue: tile rows t0-2 .. t0 are fetched and waited for outright (one memory latency per workgroup), so
+  // that the counted wait below only ever has to reason about operations issued by the loop itself: the DMA of
+  // tile row t >= t0+1 is issued in iteration t-3 and followed by exactly S(t-3) D(t+1) S(t-2) D(t+2) S(t-1).
+  // (Padding the prologue with dropped stores instead is fragile: hipcc merged three identical ones into one.)
   int t = t0 - 2;
 #pragma unroll
-  for (int d = 0; d < BAND_DEPTH; ++d) {
-    issue_dma(t + d, d);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{ 0, 0, 0, 0 }, rs_b, BAND_INVALID, 0, 0);
-  }
+  for (int d = 0; d < BAND_DEPTH; ++d) issue_dma(t + d, d);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   int F0 = allow_skip, F1 = allow_skip, F2 = allow_skip;
   const int tend = t1 + 2;                                // the back stage lags the front by two tile rows
   for (;;) {
@@ -209,6 +231,16 @@ __global__ __launch_bounds__(512) void k_dense_band(const uint8_t* __restrict__ 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#define BAND_ARGS const uint8_t* __restrict__ grey, int w, int h, int nbands, int nseg, int seg_tiles, int nframes, int min_contrast, \
+                  int hthresh, int margin, int cap, int allow_skip, uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count
+#define BAND_PASS grey, w, h, nbands, nseg, seg_tiles, nframes, min_contrast, hthresh, margin, cap, allow_skip, bin, cand, cand_count
+template <int MODE, int PRIO, int NCH>
+__global__ __launch_bounds__(512) void k_dense_band(BAND_ARGS) { dense_band_body<MODE, PRIO, NCH>(BAND_PASS); }
+// the compact-map form with an 8-chunk ring needs 50 KB of LDS: three workgroups per CU fit if the kernel stays
+// within 80 VGPRs (6 waves per SIMD); measured 1.26 -> 1.18 ms per 1024 frames with the cap (6 dwords spill)
+template <int MODE, int PRIO, int NCH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_dense_band_occ6(BAND_ARGS) { dense_band_body<MODE, PRIO, NCH>(BAND_PASS); }
+
 bool rcc_dense_band_supported(const rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin)
 {
   const rcc_config& c = h->cfg;
@@ -219,13 +251,28 @@ bool rcc_dense_band_supported(const rcc_handle* h, const uint8_t* d_grey, const 
 
 int rcc_dense_allow_skip(const rcc_handle* h);
 
+template <int MODE, int PRIO, int NCH>
+static void launch_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_out, rcc_cand* d_cand, int32_t* d_cand_count,
+                        int nbands, int nseg, int seg_tiles, int allow_skip, hipStream_t s)
+{
+  const rcc_config& c = h->cfg;
+  const long long njobs = (long long)nbands * nseg * nframes;
+  if constexpr (MODE == 2 && NCH == 8)
+    hipLaunchKernelGGL((k_dense_band_occ6<MODE, PRIO, NCH>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nseg, seg_tiles,
+                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count);
+  else
+    hipLaunchKernelGGL((k_dense_band<MODE, PRIO, NCH>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nseg, seg_tiles,
+                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count);
+}
+
+// h->want_thr (set by rcc_detect_batch): write the compact threshold map h->d_thr instead of the binary image
 hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
                                  rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s)
 {
   const rcc_config& c = h->cfg;
   const int w = c.width, ht = c.height, th = ht >> 2;
   const int nbands = (w + BAND_W - 1) / BAND_W;
-  // segments: ~8 workgroups per resident slot (2 per CU) over the launch, at least 16 tile rows each so that the
+  // segments: ~4 workgroups per resident slot over the launch, at least 16 tile rows each so that the
   // 4 warm-up / drain iterations stay a small fraction
   int seg_tiles = th;
   static const long long want_mul = getenv("RCC_DENSE_WANT") ? atoll(getenv("RCC_DENSE_WANT")) : 4;
@@ -233,17 +280,14 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
   while (seg_tiles > 16 && (long long)nbands * nframes * ((th + seg_tiles - 1) / seg_tiles) < want) seg_tiles = (seg_tiles + 1) / 2;
   const int nseg = (th + seg_tiles - 1) / seg_tiles;
   const int allow_skip = rcc_dense_allow_skip(h);
-  const long long njobs = (long long)nbands * nseg * nframes;
   static const int memonly = getenv("RCC_DENSE_MEMONLY") ? atoi(getenv("RCC_DENSE_MEMONLY")) : 0;
-  static const int prio = getenv("RCC_DENSE_PRIO") ? atoi(getenv("RCC_DENSE_PRIO")) : 1;
-  if (memonly)
-    hipLaunchKernelGGL((k_dense_band<1, 0>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, w, ht, nbands, nseg, seg_tiles, nframes,
-                       c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
-  else if (prio)
-    hipLaunchKernelGGL((k_dense_band<0, 1>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, w, ht, nbands, nseg, seg_tiles, nframes,
-                       c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
-  else
-    hipLaunchKernelGGL((k_dense_band<0, 0>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, w, ht, nbands, nseg, seg_tiles, nframes,
-                       c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
+  const bool narrow = (nbands == 1) && (w <= 2048);
+  const bool thr = h->want_thr && h->d_thr && !memonly;
+  h->bin_from_thr = thr ? 1 : 0;
+  if (memonly) launch_band<1, 0, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+  else if (thr && narrow) launch_band<2, 1, 8>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+  else if (thr) launch_band<2, 1, 9>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+  else if (narrow) launch_band<0, 1, 8>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+  else launch_band<0, 1, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
   return hipGetLastError();
 }

@@ -47,13 +47,30 @@ __device__ __forceinline__ long long wave_sum_i64(long long v)
   return v;
 }
 
-__device__ __forceinline__ bool ring_ok(const uint8_t* __restrict__ b, int w, int h, int x, int y)
+// binary-image value at (x, y): from the full image, or (thr != null) from the grey image and the compact
+// threshold map the band kernel wrote for rcc_detect_batch -- the same value by definition (a3)
+struct BinSrc {
+  const uint8_t* bin;     // frame's binary image, or null
+  const uint8_t* grey;    // frame's grey image
+  const uint8_t* thr;     // frame's compact map [band][tile row][RCC_THR_PITCH], or null
+  int w, th;
+  __device__ __forceinline__ int at(int x, int y) const
+  {
+    if (!thr) return bin[(size_t)y * w + x];
+    const int band = x / RCC_BAND_W;
+    const int lv = thr[((size_t)band * th + (y >> 2)) * RCC_THR_PITCH + ((x - band * RCC_BAND_W) >> 2)];
+    if (lv == 255) return 127;
+    return grey[(size_t)y * w + x] > lv ? 255 : 0;
+  }
+};
+
+__device__ __forceinline__ bool ring_ok(const BinSrc& b, int w, int h, int x, int y)
 {
   if (x < 5 || y < 5 || x >= w - 5 || y >= h - 5) return false;
   int v[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    v[k] = b[(size_t)(y + c_ring16[k][1]) * w + (x + c_ring16[k][0])];
+    v[k] = b.at(x + c_ring16[k][0], y + c_ring16[k][1]);
   }
   int tr = 0;
   bool any127 = false;
@@ -95,7 +112,8 @@ __device__ __forceinline__ int nearest_free(const grid_smem& sm, int n, int lane
   return (int)(best & 255ull);
 }
 
-__global__ __launch_bounds__(64) void k_validate_grid(const uint8_t* __restrict__ bin, int w, int h,
+__global__ __launch_bounds__(64) void k_validate_grid(const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
+                                                      const uint8_t* __restrict__ thr, int nbands, int w, int h,
                                                       const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
                                                       const double* __restrict__ pre_xy, int xj_check, int dedupe_radius,
                                                       int target_kind, int cols, int rows,
@@ -107,7 +125,11 @@ __global__ __launch_bounds__(64) void k_validate_grid(const uint8_t* __restrict_
   const int lane = threadIdx.x;
   rcc_frame_corners* out = fc + f;
   if (out->status != 0) return;   // overflow flagged by the list stage: the frame yields nothing
-  const uint8_t* b = bin + (size_t)f * w * h;
+  BinSrc b;
+  b.bin = bin ? bin + (size_t)f * w * h : nullptr;
+  b.grey = grey + (size_t)f * w * h;
+  b.thr = thr ? thr + (size_t)f * nbands * (h >> 2) * RCC_THR_PITCH : nullptr;
+  b.w = w; b.th = h >> 2;
   const int n = npre[f];
 
   // ---- a4.3 validation at the rounded refined position
@@ -341,13 +363,34 @@ __global__ __launch_bounds__(64) void k_validate_grid(const uint8_t* __restrict_
   }
 }
 
-hipError_t rcc_launch_grid(rcc_handle* h, const uint8_t* d_bin, int nframes, hipStream_t s)
+hipError_t rcc_launch_grid(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s)
 {
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
   // kept list outputs share the pnp scratch area layout: [B x 256 cand][B x 256 x 2 double]
-  hipLaunchKernelGGL(k_validate_grid, dim3(nframes), dim3(64), 0, s, d_bin, c.width, c.height,
+  const int nbands = (c.width + RCC_BAND_W - 1) / RCC_BAND_W;
+  hipLaunchKernelGGL(k_validate_grid, dim3(nframes), dim3(64), 0, s, h->bin_from_thr ? nullptr : d_bin, d_grey,
+                     h->bin_from_thr ? h->d_thr : nullptr, nbands, c.width, c.height,
                      h->d_pre, h->d_npre, h->d_pre_xy, c.xj_check, 2, c.target_kind, c.board_cols,
                      c.board_rows, h->d_fc, h->d_kept, h->d_kept_xy);
+  return hipGetLastError();
+}
+
+// the full binary image from the grey image and the compact threshold map (debug / parity taps only)
+__global__ __launch_bounds__(256) void k_expand_bin(const uint8_t* __restrict__ grey, const uint8_t* __restrict__ thr, int nbands,
+                                                    int w, int h, uint8_t* __restrict__ bin)
+{
+  const int f = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= w) return;
+  BinSrc b;
+  b.bin = nullptr; b.grey = grey + (size_t)f * w * h; b.thr = thr + (size_t)f * nbands * (h >> 2) * RCC_THR_PITCH; b.w = w; b.th = h >> 2;
+  bin[(size_t)f * w * h + (size_t)y * w + x] = (uint8_t)b.at(x, y);
+}
+hipError_t rcc_launch_expand_bin(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin, hipStream_t s)
+{
+  const rcc_config& c = h->cfg;
+  if (nframes <= 0) return hipSuccess;
+  const int nbands = (c.width + RCC_BAND_W - 1) / RCC_BAND_W;
+  hipLaunchKernelGGL(k_expand_bin, dim3((c.width + 255) / 256, c.height, nframes), dim3(256), 0, s, d_grey, h->d_thr, nbands, c.width, c.height, d_bin);
   return hipGetLastError();
 }

@@ -113,7 +113,7 @@ void rcc_destroy(rcc_handle* h)
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = { h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
+  void* ptrs[] = { h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
                    h->d_kept, h->d_kept_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
                    h->d_board_obj, h->d_img_scratch, h->d_family };
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -168,6 +168,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   for (auto& e : h->pev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   ALLOC(h->d_grey, B * px);
   ALLOC(h->d_bin, B * px);
+  ALLOC(h->d_thr, B * (size_t)((cfg->width + RCC_BAND_W - 1) / RCC_BAND_W) * (size_t)((cfg->height + 3) >> 2) * RCC_THR_PITCH);
   ALLOC(h->d_cand, B * (size_t)cfg->max_candidates * sizeof(rcc_cand));
   ALLOC(h->d_cand_count, B * sizeof(int32_t));
   ALLOC(h->d_pre, B * (size_t)h->kept_cap * sizeof(rcc_cand));
@@ -264,6 +265,7 @@ int rcc_stage_threshold_corner(rcc_handle* h, const void* d_grey, int32_t nframe
   if (!h || !d_grey || !d_bin || !d_cand || !d_cand_count || nframes < 0) return RCC_ERR_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  h->want_thr = 0;          // this entry point hands the full binary image to the caller
   HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey, nframes, (uint8_t*)d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, s));
   HIPCHK(h, hipStreamSynchronize(s));
   return RCC_OK;
@@ -276,6 +278,7 @@ int rcc_time_dense(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_b
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = h->stream;
   // the count reset (a tiny memset) is part of every launch of the pass; it stays inside
+  h->want_thr = 0;
   HIPCHK(h, hipEventRecord(h->ev[6], s));
   for (int r = 0; r < reps; ++r)
     HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey, nframes, (uint8_t*)d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, s));
@@ -312,7 +315,7 @@ static int launch_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d
   HIPCHK(h, rcc_launch_list(h, d_cand, d_cand_count, nframes, s));
   HIPCHK(h, rcc_launch_subpix(h, d_grey, nframes, s));
   if (fid) HIPCHK(h, rcc_launch_fid(h, d_grey, nframes, s));
-  else HIPCHK(h, rcc_launch_grid(h, d_bin, nframes, s));
+  else HIPCHK(h, rcc_launch_grid(h, d_grey, d_bin, nframes, s));
   if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
   if (fid) HIPCHK(h, rcc_launch_pnp_tags(h, nframes, s));
   else HIPCHK(h, rcc_launch_pnp_board(h, nframes, s));
@@ -363,6 +366,7 @@ static rcc_handle handle_view(const rcc_handle* h, int f0)
   rcc_handle v = *h;
   const size_t o = (size_t)f0, px = (size_t)h->cfg.width * h->cfg.height;
   v.d_grey += o * px; v.d_bin += o * px;
+  v.d_thr += o * (size_t)((h->cfg.width + RCC_BAND_W - 1) / RCC_BAND_W) * (size_t)((h->cfg.height + 3) >> 2) * RCC_THR_PITCH;
   v.d_cand += o * (size_t)h->cfg.max_candidates; v.d_cand_count += o;
   v.d_pre += o * (size_t)h->kept_cap; v.d_npre += o; v.d_pre_xy += o * (size_t)h->kept_cap * 2;
   v.d_kept += o * RCC_MAX_KEPT; v.d_kept_xy += o * RCC_MAX_KEPT * 2;
@@ -379,6 +383,7 @@ int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, cons
   if (nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  h->bin_from_thr = 0;      // the caller's binary image is the source
   return run_targets(h, (const uint8_t*)d_grey, (const uint8_t*)d_bin, (const rcc_cand*)d_cand,
                      (const int32_t*)d_cand_count, nframes, det, ndet, corners, s);
 }
@@ -422,12 +427,14 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
     for (int c = 0; c < nchunks; ++c) {
       const int f0 = (int)((long long)nframes * c / nchunks), f1 = (int)((long long)nframes * (c + 1) / nchunks);
       rcc_handle v = handle_view(h, f0);
+      v.want_thr = h->keep_bin ? 0 : 1;
       hipStream_t cs = h->pstream[c & 1];
       hipError_t e = rcc_launch_ingest(&v, d_frames + (size_t)f0 * h->cfg.frame_bytes, f1 - f0, v.d_grey, cs);
       if (e == hipSuccess) e = rcc_launch_dense(&v, v.d_grey, f1 - f0, v.d_bin, v.d_cand, v.d_cand_count, cs);
       if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s", hipGetErrorString(e)); return RCC_ERR_DEVICE; }
       int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, cs, false);
       if (r != RCC_OK) { snprintf(h->err, sizeof(h->err), "%s", v.err); return r; }
+      h->bin_from_thr = v.bin_from_thr;
     }
     for (int k = 0; k < 2; ++k) {
       HIPCHK(h, hipEventRecord(h->pev[1 + k], h->pstream[k]));
@@ -439,12 +446,24 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
   HIPCHK(h, hipEventRecord(h->ev[0], s));
   HIPCHK(h, rcc_launch_ingest(h, d_frames, nframes, h->d_grey, s));
   HIPCHK(h, hipEventRecord(h->ev[1], s));
+  // the stages after the dense pass sample the binary image at a few ring points per corner: the pass may leave
+  // it as the compact per-tile threshold map (1/16 of the bytes); rcc_debug_fetch_images expands it on demand
+  h->want_thr = h->keep_bin ? 0 : 1;
   HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
+  h->want_thr = 0;
   int r = run_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, det, ndet, corners, s);
   if (r != RCC_OK) return r;
   (void)hipEventElapsedTime(&h->last_ms[0], h->ev[0], h->ev[1]);
   (void)hipEventElapsedTime(&h->last_ms[1], h->ev[1], h->ev[2]);
   return RCC_OK;
+}
+
+int rcc_set_keep_binary(rcc_handle* h, int on)
+{
+  if (!h) return RCC_ERR_ARG;
+  int p = h->keep_bin;
+  h->keep_bin = on ? 1 : 0;
+  return p;
 }
 
 int rcc_set_pipeline(rcc_handle* h, int nchunks)
@@ -476,7 +495,13 @@ int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin
   HIPCHK(h, hipSetDevice(h->device));
   const size_t n = (size_t)nframes, px = (size_t)h->cfg.width * h->cfg.height;
   if (grey) HIPCHK(h, hipMemcpy(grey, h->d_grey, n * px, hipMemcpyDeviceToHost));
-  if (bin) HIPCHK(h, hipMemcpy(bin, h->d_bin, n * px, hipMemcpyDeviceToHost));
+  if (bin) {
+    if (h->bin_from_thr) {
+      HIPCHK(h, rcc_launch_expand_bin(h, h->d_grey, nframes, h->d_bin, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    HIPCHK(h, hipMemcpy(bin, h->d_bin, n * px, hipMemcpyDeviceToHost));
+  }
   if (cand) HIPCHK(h, hipMemcpy(cand, h->d_cand, n * (size_t)h->cfg.max_candidates * sizeof(rcc_cand), hipMemcpyDeviceToHost));
   if (cand_count) HIPCHK(h, hipMemcpy(cand_count, h->d_cand_count, n * sizeof(int32_t), hipMemcpyDeviceToHost));
   return RCC_OK;

@@ -8,6 +8,8 @@
 
 #define RCC_WAVE 64
 #define RCC_MAX_KEPT 256
+#define RCC_THR_PITCH 512     // bytes per tile row of one band in the compact threshold map (480 used at 1920 columns)
+#define RCC_BAND_W 1920        // output columns per band of the band kernel
 
 struct rcc_cand {  // dense-pass list entry, 8 bytes
   int16_t x, y;
@@ -36,6 +38,11 @@ struct rcc_handle {
   // scratch sized for batch_capacity frames
   uint8_t* d_grey;
   uint8_t* d_bin;
+  uint8_t* d_thr;           // compact threshold map of rcc_detect_batch: per frame [band][tile row][RCC_THR_PITCH] bytes,
+                            // one per 4x4 tile: 255 = flat tile (binary value 127), else the level (pixel > level ? 255 : 0)
+  int keep_bin;             // rcc_set_keep_binary: rcc_detect_batch writes the full binary image (default 0: the compact map)
+  int want_thr;             // set by rcc_detect_batch: the dense pass may write d_thr instead of the full binary image
+  int bin_from_thr;         // set by the dense launcher: this batch's binary image exists only as d_thr
   rcc_cand* d_cand;
   int32_t* d_cand_count;
   rcc_cand* d_pre;        // B x 256
@@ -78,7 +85,8 @@ hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, u
 hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t* d_cand_count,
                            int nframes, hipStream_t s);
 hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);
-hipError_t rcc_launch_grid(rcc_handle* h, const uint8_t* d_bin, int nframes, hipStream_t s);
+hipError_t rcc_launch_grid(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s);
+hipError_t rcc_launch_expand_bin(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin, hipStream_t s);
 hipError_t rcc_launch_fid(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_tags(rcc_handle* h, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s);
