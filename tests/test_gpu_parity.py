@@ -293,6 +293,28 @@ def test_kernel_variants_bit_identical(torch_cuda, oracle, pixfmt, w, h, n):
     det.close()
 
 
+@pytest.mark.parametrize("w,h,n", [(640, 480, 6), (1920, 1080, 3), (3840, 2160, 2)])
+def test_compact_threshold_map_identical(torch_cuda, w, h, n):
+    """detect() leaves the binary image as a per-tile threshold map by default; with rcc_set_keep_binary(1) it
+    writes the full image.  Same records either way, and fetch_images() hands back the same binary image."""
+    torch = torch_cuda
+    cfg = _make(w=w, h=h, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch, det, cfg, n, seed=77)
+    torch.cuda.synchronize()
+    det.set_keep_binary(0)
+    d0, f0 = det.detect(frames, n)
+    img0 = det.fetch_images(n)
+    det.set_keep_binary(1)
+    d1, f1 = det.detect(frames, n)
+    img1 = det.fetch_images(n)
+    assert len(d0) == len(d1) == n
+    assert d0.tobytes() == d1.tobytes() and f0.tobytes() == f1.tobytes()
+    assert (img0["bin"] == img1["bin"]).all() and (img0["grey"] == img1["grey"]).all()
+    assert set(np.unique(img0["bin"]).tolist()) <= {0, 127, 255}
+    det.close()
+
+
 def test_pipeline_chunks_identical(torch_cuda):
     """rcc_set_pipeline: the chunked two-stream form of detect() returns the records of the single pass"""
     torch = torch_cuda
