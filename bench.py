@@ -161,13 +161,19 @@ def main():
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_frame") * B   # PMC-derived, per frame x frames per launch
             except Exception:
                 traffic = None
+        # the form the detect path runs: binary image left as a per-tile threshold map (2*px -> (1 + 1/16)*px bytes)
+        det.time_dense(grey, B, None, cand, cnt, 1)
+        ms_c = det.time_dense(grey, B, None, cand, cnt, a.roofline_reps)
         # yardstick measured in the same process: a plain streaming copy of the same bytes (grey -> binary buffer)
         copy_ms = det.time_copy(grey, binm, B * px, a.roofline_reps) if (B * px) % 16 == 0 else None
         out["roofline"] = {"bound": "hbm", "kernel": "threshold+corner pass (k_dense_*)", "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "frac_of_guide_copy_6290": ach / 6290.0,
                            "traffic": traffic, "alg_bytes_per_launch": alg, "ms_per_launch": ms, "frames_per_launch": B,
                            "copy_same_bytes_ms": copy_ms, "copy_GBps": (alg / (copy_ms * 1e-3) / 1e9) if copy_ms else None,
-                           "frac_of_copy": (copy_ms / ms) if copy_ms else None}
+                           "frac_of_copy": (copy_ms / ms) if copy_ms else None,
+                           "detect_path_variant": {"what": "same pass, binary image kept as a 1-byte-per-4x4-tile threshold map (what rcc_detect_batch runs)",
+                                                   "ms_per_launch": ms_c, "alg_bytes_per_launch": (1.0 + 1.0 / 16.0) * px * B,
+                                                   "achieved": (1.0 + 1.0 / 16.0) * px * B / (ms_c * 1e-3) / 1e9}}
         det.time_ingest(frames, B, grey, 1)
         msi = det.time_ingest(frames, B, grey, max(1, a.roofline_reps // 2))
         algi = 4.0 * px * B

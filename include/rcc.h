@@ -240,7 +240,8 @@ int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, cons
  * [3] pnp, [4] d2h.  Returns the number of slots written. */
 int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n);
 /* Launch the dense pass `reps` times back to back and return the mean kernel time in ms measured
- * with HIP events on the launch stream (bench.py's roofline leg). */
+ * with HIP events on the launch stream (bench.py's roofline leg).  d_bin == NULL times the form
+ * rcc_detect_batch runs: binary image left as the compact threshold map in the handle (nframes <= batch_capacity). */
 int rcc_time_dense(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_bin, void* d_cand,
                    void* d_cand_count, int32_t reps, float* mean_ms);
 int rcc_time_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey,

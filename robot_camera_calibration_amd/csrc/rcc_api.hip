@@ -274,11 +274,13 @@ int rcc_stage_threshold_corner(rcc_handle* h, const void* d_grey, int32_t nframe
 int rcc_time_dense(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_bin, void* d_cand,
                    void* d_cand_count, int32_t reps, float* mean_ms)
 {
-  if (!h || !d_grey || !d_bin || !d_cand || !d_cand_count || nframes < 1 || reps < 1 || !mean_ms) return RCC_ERR_ARG;
+  if (!h || !d_grey || !d_cand || !d_cand_count || nframes < 1 || reps < 1 || !mean_ms) return RCC_ERR_ARG;
+  if (!d_bin && nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = h->stream;
   // the count reset (a tiny memset) is part of every launch of the pass; it stays inside
-  h->want_thr = 0;
+  h->want_thr = d_bin ? 0 : 1;      // d_bin == NULL: the form rcc_detect_batch runs (compact threshold map in the handle)
+  if (!d_bin) d_bin = h->d_bin;
   HIPCHK(h, hipEventRecord(h->ev[6], s));
   for (int r = 0; r < reps; ++r)
     HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey, nframes, (uint8_t*)d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, s));
