@@ -30,8 +30,10 @@
 
 #define BAND_WAVES 8
 #define BAND_W RCC_BAND_W
-#define BAND_RING 6
-#define BAND_DEPTH 3
+#ifndef BAND_DEPTH
+#define BAND_DEPTH 3          // tile rows of DMA in flight ahead of the front stage
+#endif
+#define BAND_RING (BAND_DEPTH + 3)   // + the row being read by the front, and the two behind it the back stage reads
 #define BAND_OPITCH 2048
 #define BAND_OBUF (4 * BAND_OPITCH)
 #define BAND_INVALID 0x7FFFFF00          // buffer offset past every frame: the access is dropped
@@ -165,7 +167,7 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
                      const int Fa, const int Fb, int& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
     // tile row t has landed in LDS for every wave (5 = the operations each wave has issued since its DMA of
     // tile row t), every wave has finished iteration t-1, and its LDS writes are visible
-    asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * BAND_DEPTH - 1) : "memory");
     const int sd = (sf + BAND_DEPTH >= BAND_RING) ? sf + BAND_DEPTH - BAND_RING : sf + BAND_DEPTH;
     const int sb2 = (sf >= 2) ? sf - 2 : sf + BAND_RING - 2;
     issue_dma(t + BAND_DEPTH, sd);       // the slot held tile row t-3, last read in iteration t-1

@@ -9,6 +9,7 @@
 // (real_preprocessing/src/corner_detections.cpp:48-54); corner order and object frame follow
 // real_preprocessing/src/camera_pose.cpp:152-161.  Definitions: DESIGN.md section 3 (a4.3, a6).
 #include "rcc_internal.h"
+#include "wave_reduce.h"
 
 #define GM 24
 #define GW (2 * GM + 1)
@@ -19,32 +20,22 @@ __constant__ int8_t c_ring16[16][2] = {
   {-5, 0}, {-5,-2}, {-4,-4}, {-2,-5}, { 0,-5}, { 2,-5}, { 4,-4}, { 5,-2}
 };
 
+// whole-wave min / max / sum: exchanges by permlane swaps and DPP (wave_reduce.h), no ds_bpermute
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    unsigned long long o = __shfl_xor(v, off, 64);
-    v = o < v ? o : v;
-  }
-  return v;
+  return wred::all_reduce64(v, [](unsigned long long a, unsigned long long b) { return a < b ? a : b; });
 }
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-  return v;
+  return (int)wred::all_reduce32((unsigned)v, [](unsigned a, unsigned b) { return (unsigned)min((int)a, (int)b); });
 }
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-  return v;
+  return (int)wred::all_reduce32((unsigned)v, [](unsigned a, unsigned b) { return (unsigned)max((int)a, (int)b); });
 }
 __device__ __forceinline__ long long wave_sum_i64(long long v)
 {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  return (long long)wred::all_reduce64((unsigned long long)v, [](unsigned long long a, unsigned long long b) { return a + b; });
 }
 
 // binary-image value at (x, y): from the full image, or (thr != null) from the grey image and the compact

@@ -319,12 +319,22 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   struct Regs { uint4 a, b, d; };
   const size_t goff_c = gin ? goff : ((size_t)min(max(gsy, 0), h - 1) * stride + (size_t)min(max(gsx, 0), w - 16) * NCH);
   const bool wave_has = __any(gact);                 // wave-uniform: does this wave convert anything?
+  // buffer addressing: a per-frame descriptor (scalar arithmetic) + this thread's constant 32-bit offset; pointer
+  // arithmetic would cost a 64-bit multiply-add per access on the vector ALU
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const int goff32 = (int)goff_c;
   auto issue = [&](int f, Regs& r) {
     if (!wave_has) return;
     const int fc = min(f, f1 - 1);
-    const uint4* p4 = reinterpret_cast<const uint4*>(frames + (size_t)fc * frame_bytes + goff_c);
-    r.a = p4[0];
-    if (NCH == 3) { r.b = p4[1]; r.d = p4[2]; }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frames + (size_t)fc * frame_bytes), 0, (int)frame_bytes, 0x00020000);
+    const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rs, goff32, 0, 0);
+    r.a = make_uint4(a.x, a.y, a.z, a.w);
+    if (NCH == 3) {
+      const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rs, goff32 + 16, 0, 0);
+      const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(rs, goff32 + 32, 0, 0);
+      r.b = make_uint4(b.x, b.y, b.z, b.w);
+      r.d = make_uint4(d.x, d.y, d.z, d.w);
+    }
   };
   const int glds_c = gact ? glds : (ST_ROWS * ST_PITCH);          // idle lanes write a dump slot past the box
   auto commit = [&](uint8_t* buf, const Regs& r) {
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
     if (!gin) gq = make_uint4(0, 0, 0, 0);
     *reinterpret_cast<uint4*>(buf + glds_c) = gq;
   };
-  uint8_t* const out0 = grey + (size_t)y * w + x0;
+  const int out_off = y * w + x0;
   auto taps = [&](int f, const uint8_t* L) {
     uint32_t sv[4];
 #pragma unroll
@@ -351,7 +361,8 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
     }
     const uint32_t lo = __builtin_amdgcn_perm(sv[1], sv[0], 0x0C0C0602u);
     const uint32_t hi = __builtin_amdgcn_perm(sv[3], sv[2], 0x06020C0Cu);
-    *reinterpret_cast<uint32_t*>(out0 + (size_t)f * w * h) = lo | hi;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(grey + (size_t)f * w * h, 0, w * h, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(lo | hi, ro, out_off, 0, 0);
   };
 
   // software pipeline, two frames of loads in flight: at step f the loads of f+2 are issued, the

@@ -72,6 +72,45 @@ __device__ __forceinline__ double all_sum(int lane, double v)
   reduce_scatter<1>(lane, &v);
   return v;
 }
+// ---- all-reduce with any commutative, associative operation on 32- or 64-bit values: own (x) and the
+// partner's (y) value at lane bit B, without ds_bpermute
+template <int B>
+__device__ __forceinline__ void pair32(unsigned v, unsigned& x, unsigned& y)
+{
+  if (B == 5) { const u32x2_t r = __builtin_amdgcn_permlane32_swap(v, v, false, false); x = r.x; y = r.y; }
+  else if (B == 4) { const u32x2_t r = __builtin_amdgcn_permlane16_swap(v, v, false, false); x = r.x; y = r.y; }
+  else if (B == 3) { x = v; y = __builtin_amdgcn_update_dpp(0u, v, 0x128, 0xf, 0xf, false); }                       // row_ror:8
+  else if (B == 2) { x = v; y = __builtin_amdgcn_update_dpp(__builtin_amdgcn_update_dpp(0u, v, 0x124, 0xf, 0xA, false), v, 0x12C, 0xf, 0x5, false); }
+  else if (B == 1) { x = v; y = __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, false); }                         // quad_perm [2,3,0,1]
+  else { x = v; y = __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, false); }                                      // quad_perm [1,0,3,2]
+}
+template <class Op>
+__device__ __forceinline__ unsigned all_reduce32(unsigned v, Op op)
+{
+  unsigned x, y;
+  pair32<5>(v, x, y); v = op(x, y);
+  pair32<4>(v, x, y); v = op(x, y);
+  pair32<3>(v, x, y); v = op(x, y);
+  pair32<2>(v, x, y); v = op(x, y);
+  pair32<1>(v, x, y); v = op(x, y);
+  pair32<0>(v, x, y); v = op(x, y);
+  return v;
+}
+template <class Op>
+__device__ __forceinline__ unsigned long long all_reduce64(unsigned long long v, Op op)
+{
+#define WRED_STEP64(B)                                                                                              \
+  {                                                                                                                 \
+    unsigned xl, yl, xh, yh;                                                                                        \
+    pair32<B>((unsigned)v, xl, yl);                                                                                 \
+    pair32<B>((unsigned)(v >> 32), xh, yh);                                                                         \
+    v = op((unsigned long long)xl | ((unsigned long long)xh << 32), (unsigned long long)yl | ((unsigned long long)yh << 32)); \
+  }
+  WRED_STEP64(5) WRED_STEP64(4) WRED_STEP64(3) WRED_STEP64(2) WRED_STEP64(1) WRED_STEP64(0)
+#undef WRED_STEP64
+  return v;
+}
+
 // value of lane `src` (compile-time) in every lane, through scalar registers
 template <int SRC>
 __device__ __forceinline__ double bcast(double v)
