@@ -123,6 +123,26 @@ def test_reference_mode_truncates_corners(torch_cuda, oracle):
     _check_batch(torch_cuda, oracle, cfg, frames, 3)
 
 
+def _cfg_contrast64(c): c.thr_min_contrast = 64          # flat-row skip refused by the host bound (25*gmax^2>>4)^2 >= harris_thresh
+def _cfg_harris_low(c): c.harris_thresh = 100000          # same, from the other side
+def _cfg_contrast8(c): c.thr_min_contrast = 8             # few flat tiles: noise counts as texture
+def _cfg_lists(c): c.nms_radius = 3; c.cand_margin = 12; c.max_kept = 200
+def _cfg_subpix7(c): c.subpix_win = 7; c.subpix_max_iter = 12
+def _cfg_subpix3(c): c.subpix_win = 3; c.subpix_eps = 1e-2
+
+
+@pytest.mark.parametrize("mod", [_cfg_contrast64, _cfg_harris_low, _cfg_contrast8, _cfg_lists, _cfg_subpix7, _cfg_subpix3],
+                         ids=["contrast64", "harris_low", "contrast8", "lists", "subpix7", "subpix3"])
+def test_pipeline_config_variations(torch_cuda, oracle, mod):
+    """every stage against the oracle under non-default thresholds / windows (incl. the settings for which the
+    dense pass must not skip flat rows)"""
+    cfg = _make(mod, B=3)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch_cuda, det, cfg, 3, seed=31)
+    det.close()
+    _check_batch(torch_cuda, oracle, cfg, frames, 3, expect_found=False)
+
+
 @pytest.mark.parametrize("w,h", [(645, 483), (322, 241), (64, 32), (67, 35), (131, 70)])
 def test_image_stages_ragged_noise(torch_cuda, oracle, w, h):
     """integer stages on noise + blobs at sizes that are not multiples of the tile: bit-exact"""
