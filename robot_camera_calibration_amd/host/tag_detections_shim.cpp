@@ -15,6 +15,7 @@
 #include <apriltag_ros/AprilTagDetectionArray.h>
 #include <vector>
 #include "rcc.h"
+#include "tag_detections_fill.h"
 
 class RccDetectorNode {
  public:
@@ -61,21 +62,7 @@ class RccDetectorNode {
     int st = rcc_detect_batch(h_, msg->data.data(), 1, RCC_MEM_HOST, det, &n, nullptr, nullptr);
     if (st != RCC_OK) { ROS_ERROR_THROTTLE(1.0, "rcc_detect_batch: %s", rcc_status_string(st)); return; }
     apriltag_ros::AprilTagDetectionArray out;
-    out.header = msg->header;
-    for (int i = 0; i < n; ++i) {
-      apriltag_ros::AprilTagDetection d;
-      d.id.push_back(det[i].id);                 // read as id[0]   (corner_detections.cpp:49)
-      d.size.push_back(det[i].size);             // read as size[0] (corner_detections.cpp:48)
-      for (int k = 0; k < 4; ++k) {              // bl, br, tr, tl  (camera_pose.cpp:123-126)
-        d.pixel_corners_x.push_back(det[i].corners[k][0]);
-        d.pixel_corners_y.push_back(det[i].corners[k][1]);
-      }
-      d.pose.header = msg->header;               // upstream field; the reference never reads it
-      d.pose.pose.pose.position.x = det[i].tvec[0];
-      d.pose.pose.pose.position.y = det[i].tvec[1];
-      d.pose.pose.pose.position.z = det[i].tvec[2];
-      out.detections.push_back(d);
-    }
+    rcc_fill_tag_detections<apriltag_ros::AprilTagDetectionArray, apriltag_ros::AprilTagDetection>(det, n, msg->header, out);
     pub_.publish(out);   // an empty array is skipped by the consumer (corner_detections.cpp:43)
   }
 

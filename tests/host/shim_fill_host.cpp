@@ -1,0 +1,41 @@
+// Host check of the message filling of the optional ROS node (robot_camera_calibration_amd/host/
+// tag_detections_fill.h) with stand-in message structs that carry only the field names the reference's
+// consumer reads (real_preprocessing/src/corner_detections.cpp:43-54).  No ROS involved.
+#include <vector>
+#include <cstring>
+#include "../../include/rcc.h"
+#include "../../robot_camera_calibration_amd/host/tag_detections_fill.h"
+
+namespace mock {
+struct Header { unsigned seq; double stamp; };
+struct Point { double x, y, z; };
+struct Pose { Point position; };
+struct PoseWithCov { Pose pose; };
+struct PoseStamped { Header header; PoseWithCov pose; };
+struct Detection {
+  std::vector<int> id;
+  std::vector<double> size;
+  std::vector<double> pixel_corners_x, pixel_corners_y;
+  PoseStamped pose;
+};
+struct Array { Header header; std::vector<Detection> detections; };
+}  // namespace mock
+
+// out: per detection 1 + 1 + 8 + 3 doubles = id, size, x0..x3, y0..y3, position; returns number of detections,
+// and replays the consumer's own reads: int(pixel_corners_x[n]) (corner_detections.cpp:53)
+extern "C" int shimfill_roundtrip(const rcc_detection* det, int n, unsigned seq, double* out, int* as_int)
+{
+  mock::Array msg;
+  mock::Header h{ seq, 1.5 };
+  rcc_fill_tag_detections<mock::Array, mock::Detection>(det, n, h, msg);
+  if (msg.header.seq != seq) return -1;
+  for (size_t i = 0; i < msg.detections.size(); ++i) {
+    const mock::Detection& d = msg.detections[i];
+    if (d.id.size() != 1 || d.size.size() != 1 || d.pixel_corners_x.size() != 4 || d.pixel_corners_y.size() != 4) return -2;
+    double* o = out + 13 * i;
+    o[0] = d.id[0]; o[1] = d.size[0];
+    for (int k = 0; k < 4; ++k) { o[2 + k] = d.pixel_corners_x[k]; o[6 + k] = d.pixel_corners_y[k]; as_int[8 * i + k] = int(d.pixel_corners_x[k]); as_int[8 * i + 4 + k] = int(d.pixel_corners_y[k]); }
+    o[10] = d.pose.pose.pose.position.x; o[11] = d.pose.pose.pose.position.y; o[12] = d.pose.pose.pose.position.z;
+  }
+  return (int)msg.detections.size();
+}

@@ -130,3 +130,35 @@ def test_yaml_detections_format(lib):
     doc = yaml.safe_load(txt)                      # what camera_pose.cpp:134-143 reads back
     assert doc["detections"][1]["targetID"] == 23 and doc["detections"][0]["corners"][2] == [31, 5]
     assert lib.rcc_yaml_detections(None, 0, 2, p(ids), p(sizes), p(corners)) == len(txt)     # size query
+
+
+def test_ros_shim_message_filling():
+    """N3: the optional ROS node's rcc_detection -> AprilTagDetectionArray filling, compiled against stand-in
+    message structs that have only the fields the reference's consumer reads (corner_detections.cpp:43-54):
+    one id, one size, four corners in the order bl, br, tr, tl, and the consumer's int() cast of them."""
+    import ctypes as C, subprocess
+    so = os.path.join(ROOT, "tests", "host", "libshimfill_host.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-o", so,
+                               os.path.join(ROOT, "tests", "host", "shim_fill_host.cpp")])
+    L = C.CDLL(so)
+    from robot_camera_calibration_amd import abi
+    n = 3
+    det = (abi.rcc_detection * n)()
+    for i in range(n):
+        det[i].frame = 0; det[i].id = 7 + i; det[i].size = 0.108 + 0.01 * i; det[i].ncorners = 4
+        for k in range(4):
+            det[i].corners[k][0] = 100.75 * (i + 1) + k; det[i].corners[k][1] = 50.25 * (i + 1) - k
+        for k in range(3):
+            det[i].tvec[k] = 0.1 * (k + 1) + i
+    out = np.zeros(13 * n); asint = np.zeros(8 * n, np.int32)
+    got = L.shimfill_roundtrip(det, n, 42, out.ctypes.data_as(C.c_void_p), asint.ctypes.data_as(C.c_void_p))
+    assert got == n
+    for i in range(n):
+        o = out[13 * i:13 * i + 13]
+        assert o[0] == 7 + i and abs(o[1] - (0.108 + 0.01 * i)) < 1e-15
+        for k in range(4):
+            assert o[2 + k] == det[i].corners[k][0] and o[6 + k] == det[i].corners[k][1]
+            assert asint[8 * i + k] == int(det[i].corners[k][0]) and asint[8 * i + 4 + k] == int(det[i].corners[k][1])
+        assert list(o[10:13]) == [det[i].tvec[0], det[i].tvec[1], det[i].tvec[2]]
+    assert L.shimfill_roundtrip(det, 0, 1, out.ctypes.data_as(C.c_void_p), asint.ctypes.data_as(C.c_void_p)) == 0   # empty array: consumer skips it
