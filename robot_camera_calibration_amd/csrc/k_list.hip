@@ -9,9 +9,14 @@
 #include "rcc_internal.h"
 
 #define LIST_MAX 4096   // max_candidates upper bound (LDS: 2 x 32 KiB)
+#define LIST_MAXH 4096  // the bucket path needs one 16-bit counter per image row
 
+// BUCKETS = 1 (height <= LIST_MAXH): counting sort by row + per-row ranking by x, and suppression scans only
+// the rows within the radius -- O(n * candidates per row band) instead of two O(n^2) passes (the order and the
+// survivors are the same: the key (y, x) is unique, and a suppressor lies within nms_radius rows by definition).
+template <int BUCKETS>
 __global__ __launch_bounds__(256) void k_list_sort_nms(const rcc_cand* __restrict__ cand,
-                                                       const int32_t* __restrict__ cand_count, int cap,
+                                                       const int32_t* __restrict__ cand_count, int cap, int height,
                                                        int nms_radius, int max_kept, int kstride,
                                                        rcc_cand* __restrict__ pre, int32_t* __restrict__ npre,
                                                        rcc_frame_corners* __restrict__ fc)
@@ -20,6 +25,8 @@ __global__ __launch_bounds__(256) void k_list_sort_nms(const rcc_cand* __restric
   __shared__ rcc_cand srt[LIST_MAX];
   __shared__ int s_cnt[256];
   __shared__ int s_off[257];
+  __shared__ __attribute__((aligned(16))) unsigned short s_start[BUCKETS ? LIST_MAXH + 2 : 2];   // first sorted index of each row (after the scan)
+  __shared__ __attribute__((aligned(16))) unsigned short s_fill[BUCKETS ? LIST_MAXH + 2 : 2];    // per-row counters
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const int count = cand_count[f];
@@ -35,21 +42,72 @@ __global__ __launch_bounds__(256) void k_list_sort_nms(const rcc_cand* __restric
     return;
   }
   const int n = count;
-  for (int i = tid; i < n; i += 256) raw[i] = cand[(size_t)f * cap + i];
-  __syncthreads();
-  // rank by key
-  for (int i = tid; i < n; i += 256) {
-    const rcc_cand e = raw[i];
-    const uint32_t key = ((uint32_t)(uint16_t)e.y << 16) | (uint16_t)e.x;
-    int rank = 0;
-    for (int j = 0; j < n; ++j) {
-      const rcc_cand o = raw[j];
-      const uint32_t k2 = ((uint32_t)(uint16_t)o.y << 16) | (uint16_t)o.x;
-      rank += (k2 < key);
+  if (BUCKETS) {
+    for (int y = tid; y <= height; y += 256) { s_fill[y] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      const rcc_cand e = cand[(size_t)f * cap + i];
+      raw[i] = e;
+      atomicAdd(reinterpret_cast<unsigned*>(s_fill) + ((unsigned)e.y >> 1), ((unsigned)e.y & 1u) ? 0x10000u : 1u);   // 16-bit counter (n <= 4096: no carry)
     }
-    srt[rank] = e;
+    __syncthreads();
+    // exclusive scan of the row counts: each thread scans a contiguous chunk of rows, then the chunk totals
+    const int rows = height + 1;
+    const int chunk = (rows + 255) / 256;
+    const int y0 = min(tid * chunk, rows), y1 = min(y0 + chunk, rows);
+    int acc = 0;
+    for (int y = y0; y < y1; ++y) acc += s_fill[y];
+    s_cnt[tid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      int a = 0;
+      for (int t = 0; t < 256; ++t) { s_off[t] = a; a += s_cnt[t]; }
+      s_off[256] = a;
+    }
+    __syncthreads();
+    acc = s_off[tid];
+    for (int y = y0; y < y1; ++y) { const int c = s_fill[y]; s_start[y] = (unsigned short)acc; acc += c; }
+    if (tid == 255) s_start[rows] = (unsigned short)n;
+    __syncthreads();
+    for (int y = tid; y <= height; y += 256) s_fill[y] = 0;
+    __syncthreads();
+    // scatter into row buckets (any order inside a bucket) ...
+    for (int i = tid; i < n; i += 256) {
+      const rcc_cand e = raw[i];
+      const unsigned y = (unsigned)e.y;
+      const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(s_fill) + (y >> 1), (y & 1u) ? 0x10000u : 1u);
+      const unsigned k = (y & 1u) ? (old >> 16) : (old & 0xFFFFu);
+      srt[s_start[y] + k] = e;
+    }
+    __syncthreads();
+    // ... then rank inside the bucket by x (unique within a row)
+    for (int i = tid; i < n; i += 256) {
+      const rcc_cand e = srt[i];
+      const int b0 = s_start[e.y], b1 = s_start[e.y + 1];
+      int rank = b0;
+      for (int j = b0; j < b1; ++j) rank += (srt[j].x < e.x);
+      raw[rank] = e;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) srt[i] = raw[i];
+    __syncthreads();
+  } else {
+    for (int i = tid; i < n; i += 256) raw[i] = cand[(size_t)f * cap + i];
+    __syncthreads();
+    // rank by key
+    for (int i = tid; i < n; i += 256) {
+      const rcc_cand e = raw[i];
+      const uint32_t key = ((uint32_t)(uint16_t)e.y << 16) | (uint16_t)e.x;
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        const rcc_cand o = raw[j];
+        const uint32_t k2 = ((uint32_t)(uint16_t)o.y << 16) | (uint16_t)o.x;
+        rank += (k2 < key);
+      }
+      srt[rank] = e;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // suppression; each thread owns a contiguous chunk so the output keeps the order
   const int chunk = (n + 255) / 256;
   const int i0 = min(tid * chunk, n), i1 = min(i0 + chunk, n);
@@ -58,7 +116,12 @@ __global__ __launch_bounds__(256) void k_list_sort_nms(const rcc_cand* __restric
   for (int i = i0; i < i1; ++i) {
     const rcc_cand e = srt[i];
     bool keep = true;
-    for (int j = 0; j < n && keep; ++j) {
+    int j0 = 0, j1 = n;
+    if (BUCKETS) {
+      j0 = s_start[max((int)e.y - nms_radius, 0)];
+      j1 = s_start[min((int)e.y + nms_radius, height) + 1];
+    }
+    for (int j = j0; j < j1 && keep; ++j) {
       if (j == i) continue;
       const rcc_cand o = srt[j];
       int dx = abs((int)o.x - (int)e.x), dy = abs((int)o.y - (int)e.y);
@@ -94,7 +157,11 @@ hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t*
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
   int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
-  hipLaunchKernelGGL(k_list_sort_nms, dim3(nframes), dim3(256), 0, s, d_cand, d_cand_count,
-                     c.max_candidates, c.nms_radius, max_kept, h->kept_cap, h->d_pre, h->d_npre, h->d_fc);
+  if (c.height <= LIST_MAXH - 1)
+    hipLaunchKernelGGL(k_list_sort_nms<1>, dim3(nframes), dim3(256), 0, s, d_cand, d_cand_count,
+                       c.max_candidates, c.height, c.nms_radius, max_kept, h->kept_cap, h->d_pre, h->d_npre, h->d_fc);
+  else
+    hipLaunchKernelGGL(k_list_sort_nms<0>, dim3(nframes), dim3(256), 0, s, d_cand, d_cand_count,
+                       c.max_candidates, c.height, c.nms_radius, max_kept, h->kept_cap, h->d_pre, h->d_npre, h->d_fc);
   return hipGetLastError();
 }
