@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* 
   __syncthreads();
   rccpnp::Pts p{ board_obj, img, need };
   __shared__ double ws[rccpnp::PNP_WS];          // the wave-uniform matrices: one copy per wavefront, in LDS
-  rccpnp::WavePar par{ lane, ws };
+  rccpnp::WavePar par{ lane, (unsigned)(uintptr_t)ws };
   double r[3], tv[3], e = 0.0;
   int it = 0;
   const int st = rccpnp::solve_pnp(par, p, to_cam(cam), cam.model, r, tv, &e, &it);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void k_pnp_generic_wave(const double* __restric
   const int lane = threadIdx.x;
   rccpnp::Pts p{ obj + 3 * (size_t)off[t], img + 2 * (size_t)off[t], npts[t] };
   __shared__ double ws[rccpnp::PNP_WS];
-  rccpnp::WavePar par{ lane, ws };
+  rccpnp::WavePar par{ lane, (unsigned)(uintptr_t)ws };
   double r[3], tv[3], e = 0.0;
   int it = 0;
   int st = rccpnp::solve_pnp(par, p, to_cam(cam), cam.model, r, tv, &e, &it);

@@ -323,8 +323,11 @@ struct SerialPar {
 namespace rccpnp {
 struct WavePar {
   int lane;
-  double* w;
-  __device__ double* ws() const { return w; }
+  unsigned ws_lds;   // LDS byte offset of the wavefront's workspace.  ws() rebuilds the pointer from it with an explicit
+                     // address-space cast, so that inside the out-of-line solver routines the accesses compile to ds_*
+                     // instructions: as a plain generic pointer they were FLAT operations, which go through the CU's
+                     // vector-memory address path (16 cycles per wave instruction, shared by the four wavefronts of a CU)
+  __device__ double* ws() const { return (double*)(__attribute__((address_space(3))) double*)(size_t)ws_lds; }
   __device__ int first() const { return lane; }
   __device__ int step() const { return 64; }
   __device__ double sum(double v) const { return wred::all_sum(lane, v); }
@@ -874,10 +877,11 @@ RCC_NI RCC_HD inline int pose_init(const Par& par, const Pts& p, const Cam& cm, 
 // A.8: CvLevMarq, (J, err) form, 6 free parameters.  `accum(prm, A, g)` returns |e|^2 and fills
 // A, g when A != null -- it is the only place the points are touched, so a caller can supply a
 // wave-parallel (or MFMA) accumulation.
-template <class Accum>
-RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* rms_sq_sum, double* ws /* PNP_WS */)
+template <class Accum, class Par>
+RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* rms_sq_sum, const Par& par)
 {
   double pprev[6], g[6], dl[6];
+  double* const ws = par.ws();                // rebuilt here (not passed in) so that the address space is known: see WavePar
   double* const A = ws;                       // 36
   double* const Ap = ws + 36;                 // 36
   double* const Lw = ws + 72;                 // 36: Cholesky factor
@@ -946,7 +950,7 @@ RCC_HD inline int solve_pnp(const Par& par, const Pts& p, const Cam& cm_in, int 
   }
   ParAccum<Par> acc{ par, p, cm };
   double ss = 0.0;
-  int it = pose_lm(prm, acc, cm.solver, &ss, par.ws());
+  int it = pose_lm(prm, acc, cm.solver, &ss, par);
   for (int k = 0; k < 3; ++k) { rvec[k] = prm[k]; tvec[k] = prm[3 + k]; }
   if (rms) *rms = sqrt(ss / p.n);
   if (iters) *iters = it;
