@@ -111,7 +111,9 @@ struct RowPipe {
   __device__ __forceinline__ void row(const int r, const int k, const unsigned G, const SobelRow& a, const SobelRow& b, SobelRow& n, const int rmask)
   {
     // ---- stage A (row r): horizontal Sobel partials, natural-order pixel pairs
-    const unsigned GL = (unsigned)from_left((int)G, (int)G), GR = (unsigned)from_right((int)G, (int)G);
+    // zero for the lanes without a neighbour: that only changes lane 0's pixel -1 and lane 63's pixel 4, which
+    // reach nothing outside those (halo) lanes' own sums
+    const unsigned GL = (unsigned)from_left0((int)G), GR = (unsigned)from_right0((int)G);
     const u16x2 n0 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C010C00u));    // [p0,p1]
     const u16x2 n1 = as_u(__builtin_amdgcn_perm(0u, G, 0x0C030C02u));    // [p2,p3]
     const u16x2 mm = as_u(__builtin_amdgcn_perm(0u, G, 0x0C020C01u));    // [p1,p2]
@@ -158,8 +160,8 @@ struct RowPipe {
       LRow Rn;
       Rn.r0 = rmask ? INT32_MIN : __mul24(A0, C0) - __mul24(B0, B0) - (int)(__umul24(tr0, tr0) >> 4);
       Rn.r2 = rmask ? INT32_MIN : __mul24(A2, C2) - __mul24(B2, B2) - (int)(__umul24(tr2, tr2) >> 4);
-      Rn.rL = from_left(Rn.r2, INT32_MIN);
-      Rn.rR = from_right(Rn.r0, INT32_MIN);
+      Rn.rL = from_left0(Rn.r2);           // lanes 0 / 63 (halo, never selected) see 0 instead of a neighbour
+      Rn.rR = from_right0(Rn.r0);
       hprev = hc;
       // selection on lattice row yc = rho - 4 = r - 5 (rows Ra = yc-2, Rb = yc, Rn = yc+2)
       const int yc = r - 5;
