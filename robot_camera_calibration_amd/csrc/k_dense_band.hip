@@ -81,6 +81,7 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
   const int x0 = X0 + wv * STRIP_USE - 8 + 4 * lane;           // first pixel of this lane
   const int xl = min(max(x0, 0), w - 4);                       // clamped column (as the strip kernel)
   const bool lane_out = (lane >= 2) && (lane <= 62) && (x0 >= X0) && (x0 < X1);
+  const bool lane_core = (lane >= 2) && (lane <= 62);
   const bool wave_on = (X0 + wv * STRIP_USE) < X1;             // wave-uniform: does this window hold band pixels?
   const uint8_t* gf = grey + (size_t)f * w * h;
   // output: the frame's binary image, or (THR) this band's slice of the frame's compact threshold map
@@ -188,7 +189,7 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
       const int tau = t - 2;
       if (THR) stage_thr(ob, flatB ? 255 : thrB);            // tile row tau's level (thrB <= 254 when not flat)
       if (tau >= t0 - 2) {
-        if (__any(!(Fa && Fb && Fn))) {
+        if (__any(lane_core && !(Fa && Fb && Fn))) {   // halo lanes do not vote: nothing they hold reaches an output
           if (PRIO) __builtin_amdgcn_s_setprio(2);          // the wave on the critical path of this iteration
           const Tile4 B = read_tile(sb2);
           if (!THR) {

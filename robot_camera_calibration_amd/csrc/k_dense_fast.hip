@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
   const int x0 = xs + 4 * lane;                         // first pixel of this lane
   const int xl = min(max(x0, 0), w - 4);                // clamped load column
   const bool lane_out = (lane >= 2) && (lane <= 62) && (x0 >= 0) && (x0 < w);
+  const bool lane_core = (lane >= 2) && (lane <= 62);
   const uint8_t* gf = grey + (size_t)f * w * h;
   uint8_t* bo = bin + (size_t)f * w * h;
   if (margin < 6) margin = 6;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
     const int tau = t - 2;
     if (tau >= t0 - 2) {
       const bool out_row = (tau >= t0) && (tau < t1) && lane_out;
-      if (__any(!(Fa && Fb && Fn))) {
+      if (__any(lane_core && !(Fa && Fb && Fn))) {   // halo lanes do not vote: nothing they hold reaches an output
         if (out_row) {
           const Thr4 thr(thrB, flatB);
           store_row(4 * tau + 0, thr(Bc.g0));
