@@ -71,10 +71,14 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
       const int idx = lane + 64 * t;
       if (idx < pw * pw) {
         const uint8_t* p = pc + poff[t];
-        double t0 = a00 * (double)p[0];
-        double t1 = a01 * (double)p[1];
-        double t2 = a10 * (double)p[w];
-        double t3 = a11 * (double)p[w + 1];
+        // the two taps of a row with one (unaligned) 16-bit load
+        unsigned short r0, r1;
+        __builtin_memcpy(&r0, p, 2);
+        __builtin_memcpy(&r1, p + w, 2);
+        double t0 = a00 * (double)(r0 & 255);
+        double t1 = a01 * (double)(r0 >> 8);
+        double t2 = a10 * (double)(r1 & 255);
+        double t3 = a11 * (double)(r1 >> 8);
         double s = t0 + t1;
         s = s + t2;
         s = s + t3;
