@@ -219,6 +219,9 @@ int rcc_set_dense_skip(rcc_handle* h, int on);
  * rcc_detect_batch materialise the full binary image (as rcc_stage_threshold_corner always does).  Returns the
  * previous setting. */
 int rcc_set_keep_binary(rcc_handle* h, int on);
+/* 1 (default): the checkerboard path runs lattice indexing and the pose solve of a frame in one kernel (one
+ * wavefront per frame); 0: as two kernels.  Same results.  Returns the previous setting. */
+int rcc_set_fuse_grid_pnp(rcc_handle* h, int on);
 /* rcc_detect_batch pipeline: n > 1 cuts a batch into n chunks (at least 64 frames each) that alternate over two
  * internal streams, so that the per-frame dependency chains of target identification and pose run under the
  * bandwidth-bound passes of the next chunk; 0 or 1 = one pass on one stream (per-stage times of rcc_last_timings
@@ -237,7 +240,8 @@ int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, cons
 
 /* timings of the last rcc_detect_batch / stage call, milliseconds, measured with HIP events on the
  * stream the kernels were launched on: [0] ingest, [1] dense threshold+corner, [2] list+subpix+grid,
- * [3] pnp, [4] d2h.  Returns the number of slots written. */
+ * [3] pnp, [4] d2h (with rcc_set_fuse_grid_pnp(1), the default for checkerboards, the grid stage runs inside the
+ * pose kernel and is counted in [3]).  Returns the number of slots written. */
 int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n);
 /* Launch the dense pass `reps` times back to back and return the mean kernel time in ms measured
  * with HIP events on the launch stream (bench.py's roofline leg).  d_bin == NULL times the form

@@ -71,6 +71,8 @@ def load_library():
     L.rcc_set_dense_skip.restype = C.c_int
     L.rcc_time_copy.argtypes = [P, P, P, C.c_int64, I, C.POINTER(C.c_float)]
     L.rcc_time_copy.restype = C.c_int
+    L.rcc_set_fuse_grid_pnp.argtypes = [P, C.c_int]
+    L.rcc_set_fuse_grid_pnp.restype = C.c_int
     L.rcc_set_keep_binary.argtypes = [P, C.c_int]
     L.rcc_set_keep_binary.restype = C.c_int
     L.rcc_set_pipeline.argtypes = [P, C.c_int]
@@ -100,7 +102,7 @@ EXPORTED_SYMBOLS = (
     "rcc_default_config", "rcc_create", "rcc_destroy", "rcc_status_string", "rcc_last_device_error",
     "rcc_abi_version", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
     "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_set_dense_variant",
-    "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_set_dense_skip", "rcc_set_keep_binary", "rcc_set_pipeline", "rcc_time_copy", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
+    "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_set_dense_skip", "rcc_set_keep_binary", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline", "rcc_time_copy", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
     "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch", "rcc_debug_calib_copy",
     "rcc_debug_pnp_probe",
 )
@@ -262,6 +264,9 @@ class Detector:
         ms = C.c_float(0)
         self._chk(self._L.rcc_time_copy(self._h, _ptr(d_src), _ptr(d_dst), int(nbytes), int(reps), C.byref(ms)), "rcc_time_copy")
         return float(ms.value)
+
+    def set_fuse_grid_pnp(self, on):
+        return self._L.rcc_set_fuse_grid_pnp(self._h, int(on))
 
     def set_keep_binary(self, on):
         """1: detect() materialises the full binary image; 0 (default): the compact per-tile threshold map"""

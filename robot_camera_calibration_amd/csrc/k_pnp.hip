@@ -18,6 +18,7 @@
 // (measured on MI355X; -O1, the host build and this out-of-line form all match the oracle to 1e-15).
 #define RCC_PNP_NOINLINE 1
 #include "pnp_core.h"
+#include "grid_frame.h"
 
 static __device__ __forceinline__ rccpnp::Cam to_cam(const rcc_cam& c)
 {
@@ -83,28 +84,24 @@ __global__ __launch_bounds__(64) void k_pnp_board(const rcc_frame_corners* __res
   ndet[f] = 1;
 }
 
-// one wavefront per frame
-__global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* __restrict__ fc, int nframes,
-                                                       const double* __restrict__ board_obj, int cols, int rows,
-                                                       double square, int board_id, int reference_mode,
-                                                       rcc_cam cam, double* __restrict__ img_scratch,
-                                                       rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
+// one wavefront per frame: pose of the board from its ordered corners.  XY(k, x, y) hands out corner k (row-major
+// lattice index); img: 2 * need doubles the solver reads its image points from (per frame, any memory)
+template <class XY>
+__device__ __forceinline__ void board_pose_frame(const int f, const int lane, XY xy_of, double* __restrict__ img,
+                                                 const double* __restrict__ board_obj, int cols, int rows,
+                                                 double square, int board_id, int reference_mode, const rcc_cam& cam,
+                                                 double* ws, rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
 {
-  const int f = blockIdx.x;
-  const int lane = threadIdx.x;
-  const rcc_frame_corners* c = fc + f;
   const int need = cols * rows;
-  if (c->status != 0 || c->ncorners != need) { if (lane == 0) ndet[f] = 0; return; }
-  double* img = img_scratch + (size_t)f * 2 * RCC_MAX_BOARD_CORNERS;
   for (int k = lane; k < need; k += 64) {
-    double x = c->xy[k][0], y = c->xy[k][1];
+    double x, y;
+    xy_of(k, x, y);
     if (reference_mode) { x = (double)(int)x; y = (double)(int)y; }   // corner_detections.cpp:53-54
     img[2 * k] = x;
     img[2 * k + 1] = y;
   }
   __syncthreads();
   rccpnp::Pts p{ board_obj, img, need };
-  __shared__ double ws[rccpnp::PNP_WS];          // the wave-uniform matrices: one copy per wavefront, in LDS
   rccpnp::WavePar par{ lane, (unsigned)(uintptr_t)ws };
   double r[3], tv[3], e = 0.0;
   int it = 0;
@@ -117,7 +114,7 @@ __global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* 
     d.ncorners = need;
     d.size = square;
     const int idx[4] = { (rows - 1) * cols, (rows - 1) * cols + cols - 1, cols - 1, 0 };   // bl, br, tr, tl
-    for (int k = 0; k < 4; ++k) { d.corners[k][0] = c->xy[idx[k]][0]; d.corners[k][1] = c->xy[idx[k]][1]; }
+    for (int k = 0; k < 4; ++k) xy_of(idx[k], d.corners[k][0], d.corners[k][1]);
     for (int k = 0; k < 3; ++k) { d.rvec[k] = r[k]; d.tvec[k] = tv[k]; }
     d.rms = e;
     d.pnp_status = st;
@@ -125,6 +122,46 @@ __global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* 
     det[f] = d;
     ndet[f] = 1;
   }
+}
+
+__global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* __restrict__ fc, int nframes,
+                                                       const double* __restrict__ board_obj, int cols, int rows,
+                                                       double square, int board_id, int reference_mode,
+                                                       rcc_cam cam, double* __restrict__ img_scratch,
+                                                       rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
+{
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x;
+  const rcc_frame_corners* c = fc + f;
+  if (c->status != 0 || c->ncorners != cols * rows) { if (lane == 0) ndet[f] = 0; return; }
+  __shared__ double ws[rccpnp::PNP_WS];          // the wave-uniform matrices: one copy per wavefront, in LDS
+  board_pose_frame(f, lane, [&](int k, double& x, double& y) { x = c->xy[k][0]; y = c->xy[k][1]; },
+                   img_scratch + (size_t)f * 2 * RCC_MAX_BOARD_CORNERS, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, det, ndet);
+}
+
+// a4.3 + a6 + a7 of one frame in one wavefront: board validation / lattice indexing (grid_frame.h), then the pose
+// from the lattice it leaves in LDS.  Both stages are single dependency chains per frame; run as two kernels the
+// second waits for the slowest frame of the first.
+__global__ __launch_bounds__(64) void k_grid_pnp(const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
+                                                 const uint8_t* __restrict__ thr, int nbands, int w, int h,
+                                                 const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
+                                                 const double* __restrict__ pre_xy, int xj_check, int dedupe_radius,
+                                                 int cols, int rows, rcc_frame_corners* __restrict__ fc,
+                                                 rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out,
+                                                 const double* __restrict__ board_obj, double square, int board_id, int reference_mode,
+                                                 rcc_cam cam, rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
+{
+  __shared__ grid_smem sm;
+  __shared__ double ws[rccpnp::PNP_WS];
+  __shared__ double s_img[2 * RCC_MAX_BOARD_CORNERS];
+  const int f = blockIdx.x;
+  const int lane = threadIdx.x;
+  const bool found = grid_frame(sm, f, lane, bin, grey, thr, nbands, w, h, pre, npre, pre_xy, xj_check, dedupe_radius, RCC_TARGET_CHECKERBOARD,
+                                cols, rows, fc, kept_out, kept_xy_out);
+  __syncthreads();
+  if (!found) { if (lane == 0) ndet[f] = 0; return; }       // wave-uniform
+  board_pose_frame(f, lane, [&](int k, double& x, double& y) { const int o = sm.order[k]; x = sm.xy[2 * o]; y = sm.xy[2 * o + 1]; },
+                   s_img, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, det, ndet);
 }
 
 __global__ __launch_bounds__(64) void k_pnp_generic_wave(const double* __restrict__ obj, const double* __restrict__ img,
@@ -229,6 +266,29 @@ hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s)
                        c.board_cols, c.board_rows, c.board_square, c.board_id, c.reference_mode, cam,
                        h->d_img_scratch, h->d_det, h->d_ndet);
   return hipGetLastError();
+}
+
+// grid + board pose in one launch (wave per frame); same outputs as rcc_launch_grid followed by rcc_launch_pnp_board
+hipError_t rcc_launch_grid_pnp(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s)
+{
+  const rcc_config& c = h->cfg;
+  if (nframes <= 0) return hipSuccess;
+  rcc_cam cam;
+  cam.fx = c.K[0]; cam.cx = c.K[2]; cam.fy = c.K[4]; cam.cy = c.K[5];
+  for (int i = 0; i < 8; ++i) cam.D[i] = c.D[i];
+  cam.model = h->undist ? RCC_DIST_NONE : c.dist_model;
+  cam.solver = h->pnp_solver;
+  const int nbands = (c.width + RCC_BAND_W - 1) / RCC_BAND_W;
+  hipLaunchKernelGGL(k_grid_pnp, dim3(nframes), dim3(64), 0, s, h->bin_from_thr ? nullptr : d_bin, d_grey,
+                     h->bin_from_thr ? h->d_thr : nullptr, nbands, c.width, c.height, h->d_pre, h->d_npre, h->d_pre_xy, c.xj_check, 2,
+                     c.board_cols, c.board_rows, h->d_fc, h->d_kept, h->d_kept_xy, h->d_board_obj, c.board_square, c.board_id,
+                     c.reference_mode, cam, h->d_det, h->d_ndet);
+  return hipGetLastError();
+}
+bool rcc_grid_pnp_applicable(const rcc_handle* h)
+{
+  const rcc_config& c = h->cfg;
+  return c.target_kind == RCC_TARGET_CHECKERBOARD && c.board_cols * c.board_rows > 8 && h->pnp_variant != 0;
 }
 
 hipError_t rcc_launch_rodrigues(int dir, const double* d_in, int n, double* d_out, hipStream_t s)

@@ -141,6 +141,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->device = cfg->device;
   h->undist = cfg->undistort && cfg->dist_model != RCC_DIST_NONE;
   h->dense_variant = -1;
+  h->fuse_grid_pnp = 1;
   h->pipeline_chunks = 1;   // measured: chunking the batch over two streams is slower at every chunk count
   h->ingest_variant = -1;
   h->dense_skip = 1;
@@ -316,10 +317,12 @@ static int launch_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d
   if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
   HIPCHK(h, rcc_launch_list(h, d_cand, d_cand_count, nframes, s));
   HIPCHK(h, rcc_launch_subpix(h, d_grey, nframes, s));
+  const bool fused = !fid && h->fuse_grid_pnp && rcc_grid_pnp_applicable(h);   // lattice indexing + pose in one launch
   if (fid) HIPCHK(h, rcc_launch_fid(h, d_grey, nframes, s));
-  else HIPCHK(h, rcc_launch_grid(h, d_grey, d_bin, nframes, s));
+  else if (!fused) HIPCHK(h, rcc_launch_grid(h, d_grey, d_bin, nframes, s));
   if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
   if (fid) HIPCHK(h, rcc_launch_pnp_tags(h, nframes, s));
+  else if (fused) HIPCHK(h, rcc_launch_grid_pnp(h, d_grey, d_bin, nframes, s));
   else HIPCHK(h, rcc_launch_pnp_board(h, nframes, s));
   if (timed) HIPCHK(h, hipEventRecord(h->ev[4], s));
   return RCC_OK;
@@ -458,6 +461,14 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
   (void)hipEventElapsedTime(&h->last_ms[0], h->ev[0], h->ev[1]);
   (void)hipEventElapsedTime(&h->last_ms[1], h->ev[1], h->ev[2]);
   return RCC_OK;
+}
+
+int rcc_set_fuse_grid_pnp(rcc_handle* h, int on)
+{
+  if (!h) return RCC_ERR_ARG;
+  int p = h->fuse_grid_pnp;
+  h->fuse_grid_pnp = on ? 1 : 0;
+  return p;
 }
 
 int rcc_set_keep_binary(rcc_handle* h, int on)

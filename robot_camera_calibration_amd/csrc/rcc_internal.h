@@ -40,6 +40,7 @@ struct rcc_handle {
   uint8_t* d_bin;
   uint8_t* d_thr;           // compact threshold map of rcc_detect_batch: per frame [band][tile row][RCC_THR_PITCH] bytes,
                             // one per 4x4 tile: 255 = flat tile (binary value 127), else the level (pixel > level ? 255 : 0)
+  int fuse_grid_pnp;        // 1 (default): board validation / indexing and pose in one kernel (checkerboard, wave-per-board solver)
   int keep_bin;             // rcc_set_keep_binary: rcc_detect_batch writes the full binary image (default 0: the compact map)
   int want_thr;             // set by rcc_detect_batch: the dense pass may write d_thr instead of the full binary image
   int bin_from_thr;         // set by the dense launcher: this batch's binary image exists only as d_thr
@@ -90,6 +91,8 @@ hipError_t rcc_launch_expand_bin(rcc_handle* h, const uint8_t* d_grey, int nfram
 hipError_t rcc_launch_fid(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_tags(rcc_handle* h, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s);
+hipError_t rcc_launch_grid_pnp(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s);
+bool rcc_grid_pnp_applicable(const rcc_handle* h);
 hipError_t rcc_launch_pnp_generic(rcc_handle* h, const double* d_obj, const double* d_img,
                                   const int32_t* d_off, const int32_t* d_npts, int ntargets,
                                   rcc_cam cam, double* d_rvec, double* d_tvec, double* d_rms,

@@ -335,6 +335,24 @@ def test_compact_threshold_map_identical(torch_cuda, w, h, n):
     det.close()
 
 
+def test_fused_grid_pnp_identical(torch_cuda):
+    """lattice indexing + pose in one kernel (default) vs two kernels: the same records and corner tables"""
+    torch = torch_cuda
+    n = 40
+    cfg = _make(w=640, h=480, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch, det, cfg, n, seed=909)
+    frames[3].zero_()                      # a frame without a board
+    torch.cuda.synchronize()
+    det.set_fuse_grid_pnp(1)
+    d1, f1 = det.detect(frames, n)
+    det.set_fuse_grid_pnp(0)
+    d0, f0 = det.detect(frames, n)
+    assert len(d1) == len(d0) >= n - 2 and 3 not in set(d1["frame"].tolist())
+    assert d1.tobytes() == d0.tobytes() and f1.tobytes() == f0.tobytes()
+    det.close()
+
+
 def test_pipeline_chunks_identical(torch_cuda):
     """rcc_set_pipeline: the chunked two-stream form of detect() returns the records of the single pass"""
     torch = torch_cuda
