@@ -101,12 +101,12 @@ __device__ __forceinline__ int nearest_free(const grid_smem& sm, int n, int lane
 // returns true when the board lattice was found: its corners are then also at sm.xy[2 * sm.order[k]], k = 0..cols*rows-1
 __device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int lane,
                                            const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
-                                                      const uint8_t* __restrict__ thr, int nbands, int w, int h,
-                                                      const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                                      const double* __restrict__ pre_xy, int xj_check, int dedupe_radius,
-                                                      int target_kind, int cols, int rows,
-                                                      rcc_frame_corners* __restrict__ fc,
-                                                      rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out)
+                                           const uint8_t* __restrict__ thr, int nbands, int w, int h,
+                                           const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
+                                           const double* __restrict__ pre_xy, int xj_check, int dedupe_radius,
+                                           int target_kind, int cols, int rows,
+                                           rcc_frame_corners* __restrict__ fc,
+                                           rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out)
 {
   rcc_frame_corners* out = fc + f;
   if (out->status != 0) return false;   // overflow flagged by the list stage: the frame yields nothing
