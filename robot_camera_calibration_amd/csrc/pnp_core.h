@@ -231,6 +231,56 @@ RCC_HD inline void spd_solve(int solver, const double* A, const double* b, doubl
   }
 }
 
+// max_a (A^-1)[a][a] of a symmetric positive definite N x N matrix through its Cholesky factor: A^-1 = L^-T L^-1, so
+// the a-th diagonal entry is the squared norm of column a of L^-1 (forward substitution on e_a).  Returns 0 when a
+// pivot says the matrix is numerically rank deficient (the caller then takes the eigen-decomposition, which drops
+// those directions as the published algorithm does).
+template <int N>
+RCC_HD inline int inv_diag_max_spd(const double* A, double* L /* N*N workspace */, double* maxdiag)
+{
+  double dmax = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) if (A[i * N + i] > dmax) dmax = A[i * N + i];
+  if (!(dmax > 0.0)) return 0;
+  const double tiny = 1e-13 * dmax;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double d = A[j * N + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
+    if (!(d > tiny)) ok = false;
+    const double idj = 1.0 / sqrt(d > tiny ? d : 1.0);
+    L[j * N + j] = idj;                       // 1 / L_jj
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double t = A[i * N + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * N + k] * L[j * N + k];
+      L[i * N + j] = t * idj;
+    }
+  }
+  if (!ok) return 0;
+  double best = 0.0;
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    double y[N];
+    y[a] = L[a * N + a];
+    double s = y[a] * y[a];
+#pragma unroll
+    for (int k = a + 1; k < N; ++k) {
+      double t = 0.0;
+#pragma unroll
+      for (int j = a; j < k; ++j) t -= L[k * N + j] * y[j];
+      y[k] = t * L[k * N + k];
+      s += y[k] * y[k];
+    }
+    if (s > best) best = s;
+  }
+  *maxdiag = best;
+  return 1;
+}
+
 // Eigenvector of the smallest eigenvalue of a symmetric positive semi-definite n x n matrix
 // (n <= 9): shifted inverse iteration on a Cholesky factor of M + delta*I.  The DLT matrix L^T L
 // has one eigenvalue that is (numerically) zero for consistent correspondences and a gap of many
@@ -594,7 +644,8 @@ RCC_HD inline double homography_accumulate(const Par& par, const double* h, cons
   if (rinf) *rinf = par.max(ri);
   double* const red = par.ws() + 192;         // 45 totals
   if (A) {
-    par.template reduce_store<45>(q, red);
+    par.template reduce_store<32>(q, red);            // 45 = 32 + 13: two halvings (31 + 17 exchange steps, 64 + 32 live
+    par.template reduce_store<13>(q + 32, red + 32);  // registers) instead of one padded to 64 (63 steps, 128 registers)
     par.template unpack_sym<8>(red, A);
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = red[36 + r];
@@ -652,23 +703,35 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
       double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1.0) + 2.0;
       nu = nu < 2.0 ? 2.0 : (nu > 10.0 ? 10.0 : nu);
       if (lambda == 0.0) {
-        double* const T = par.ws() + 64;      // Ap and the factor are dead here
-        double* const V = par.ws() + 128;
-        double w[8];
-#pragma unroll
-        for (int i = 0; i < 64; ++i) T[i] = A[i];
-        jacobi_eigen_sym(P, T, w, V);
-        double thr = 0.0;
-#pragma unroll
-        for (int i = 0; i < P; ++i) thr += fabs(w[i]);
-        thr *= 2.0 * DBL_EPSILON;
+#ifdef RCC_PNP_TRACE_EIGEN
+        RCC_PNP_TRACE_EIGEN(iter);
+#endif
+        // lc = 1 / max diagonal entry of pinv(JtJ) (LMSolver takes it from an SVD).  Every solve comes through here
+        // once, near convergence; as a cyclic Jacobi decomposition of the 8x8 matrix it was three quarters of the
+        // whole pose solve (~45 k of 60 k instructions).  For a positive definite JtJ the same number comes out of
+        // a Cholesky factor; the decomposition remains for solver 0 and for a rank-deficient matrix.
         double maxval = DBL_EPSILON;
+        double mdiag = 0.0;
+        if (cm.solver == 1 && inv_diag_max_spd<8>(A, Lw, &mdiag)) {
+          if (mdiag > maxval) maxval = mdiag;
+        } else {
+          double* const T = par.ws() + 64;    // Ap and the factor are dead here
+          double* const V = par.ws() + 128;
+          double w[8];
 #pragma unroll
-        for (int a = 0; a < P; ++a) {
-          double s = 0.0;
+          for (int i = 0; i < 64; ++i) T[i] = A[i];
+          jacobi_eigen_sym(P, T, w, V);
+          double thr = 0.0;
 #pragma unroll
-          for (int i = 0; i < P; ++i) if (fabs(w[i]) > thr) s += V[i * P + a] * V[i * P + a] / w[i];
-          if (fabs(s) > maxval) maxval = fabs(s);
+          for (int i = 0; i < P; ++i) thr += fabs(w[i]);
+          thr *= 2.0 * DBL_EPSILON;
+#pragma unroll
+          for (int a = 0; a < P; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < P; ++i) if (fabs(w[i]) > thr) s += V[i * P + a] * V[i * P + a] / w[i];
+            if (fabs(s) > maxval) maxval = fabs(s);
+          }
         }
         lambda = lc = 1.0 / maxval;
         nu *= 0.5;
@@ -740,7 +803,8 @@ RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const dou
 #pragma unroll
       for (int k = j; k < 9; ++k, ++q) ll[q] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
   }
-  par.template reduce_store<45>(ll, par.ws() + 192);
+  par.template reduce_store<32>(ll, par.ws() + 192);
+  par.template reduce_store<13>(ll + 32, par.ws() + 192 + 32);
   par.template unpack_sym<9>(par.ws() + 192, LtL);
   double H0[9], T[9];
   if (!(cm.solver == 1 && smallest_eigvec_psd<9>(LtL, H0, par.ws() + 81))) {
