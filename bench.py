@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--dense-variant", type=int, default=-1)
     ap.add_argument("--ingest-variant", type=int, default=-1)
     ap.add_argument("--roofline-reps", type=int, default=5)
+    ap.add_argument("--sync-steps", action="store_true", help="time K synchronous detect() calls instead of the submit/collect stream of K batches")
     ap.add_argument("--pipeline", type=int, default=1, help="chunks of the detector's two-stream pipeline per step (1: single pass)")
     ap.add_argument("--fiducials", default="", help="BASELINE.json configs[4]-style run: GXxGY planar grid of square fiducials per frame, e.g. 6x4")
     ap.add_argument("--fisheye", action="store_true", help="BASELINE.json configs[3]-style run: fisheye model (use with --width 3840 --height 2160 --batch 256)")
@@ -109,8 +110,19 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     found = 0
-    for _ in range(a.steps):
-        found = step()
+    if a.sync_steps:
+        for _ in range(a.steps):
+            found = step()
+    else:
+        # the streaming form of the same K steps (rcc_detect_batch_submit / _collect): batch k+1 is launched before
+        # the host unpacks batch k, so the device does not idle during the unpack and the exchange of the records.
+        # Every step's work -- all kernels, the device-to-host copy, the unpack, the all_gather -- is inside the region.
+        det.submit(frames, B)
+        for k in range(a.steps):
+            if k + 1 < a.steps:
+                det.submit(frames, B)
+            dets, _ = det.collect()
+            found = gather.run(dets)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -119,6 +131,22 @@ def main():
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # the same K steps as synchronous detect() calls, for comparison (reported, not `value`)
+    sync_fps = None
+    if not a.sync_steps:
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1s = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dts = torch.tensor([time.perf_counter() - t1s], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+        sync_fps = world * B * a.steps / float(dts.item())
     # per-stage times: one extra (untimed) step as a single pass on one stream -- in the pipelined step the stages of
     # different chunks overlap, so they have no separate durations
     prev = det.set_pipeline(1)
@@ -139,7 +167,7 @@ def main():
                        "frames_per_step_per_gpu": B,
                        "target": ("%dx%d square fiducials of 0.10 m per frame (build family36b), 4-point PnP per tag" % fid) if fid else "8x6 inner-corner checkerboard, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
                        "parallelism": "frame-sharded, 1 process per GPU, 1 all_gather of pose records per step"},
-            "targets_found_in_last_step": int(found), "targets_expected_per_step": int(world * B * (fid[0] * fid[1] if fid else 1)), "stage_ms_single_pass": timings, "pipeline_chunks": a.pipeline,
+            "targets_found_in_last_step": int(found), "targets_expected_per_step": int(world * B * (fid[0] * fid[1] if fid else 1)), "stage_ms_single_pass": timings, "pipeline_chunks": a.pipeline, "step_form": "sync detect()" if a.sync_steps else "submit/collect, one batch ahead", "value_with_sync_steps": sync_fps,
         }
 
     # ---- roofline of the threshold+corner pass (the kernel BASELINE.json's north_star names) and

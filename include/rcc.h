@@ -36,7 +36,8 @@ enum {
   RCC_ERR_UNSUPPORTED = -2,  /* valid request this build does not implement */
   RCC_ERR_DEVICE = -3,       /* HIP runtime error; see rcc_last_device_error */
   RCC_ERR_CAPACITY = -4,     /* nframes / ntargets exceeds what the handle was created for */
-  RCC_ERR_NOMEM = -5
+  RCC_ERR_NOMEM = -5,
+  RCC_ERR_STATE = -6         /* call out of order: submit with both result slots in flight, collect with nothing submitted */
 };
 
 /* ---- enums --------------------------------------------------------------------------------- */
@@ -197,6 +198,18 @@ int rcc_rodrigues_v2m_batch(rcc_handle* h, const double* rvec, int32_t n, double
 int rcc_rodrigues_m2v_batch(rcc_handle* h, const double* R9, int32_t n, double* rvec);
 
 /* ---- stage-level entry points (device pointers; used by the parity tests and the bench) ------ */
+/* Asynchronous form of rcc_detect_batch for a stream of batches: submit launches everything for a batch (incl.
+ * the copy of the records into one of two pinned result slots) and returns; collect waits for the OLDEST
+ * outstanding submission and unpacks its records (same order and contents as rcc_detect_batch).  At most two
+ * submissions may be outstanding, so the host can unpack batch k while the device runs batch k+1:
+ *     submit(b0); for (k = 1; k < n; ++k) { submit(b_k); collect(&out[k-1]); }  collect(&out[n-1]);
+ * `frames` (and `corners`, if given: it is filled by the submission's own copy) must stay valid until that
+ * submission has been collected.  RCC_ERR_STATE when called out of order; rcc_detect_batch itself refuses to run
+ * while submissions are outstanding. */
+int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, int32_t frames_mem,
+                            rcc_frame_corners* corners, void* stream);
+int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet);
+
 /* a1+a2: ingest = BGR->grey (+ undistort when cfg.undistort).  src/dst device pointers;
  * dst is nframes tightly packed width*height u8 images. */
 int rcc_stage_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey, void* stream);

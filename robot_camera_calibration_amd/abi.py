@@ -9,7 +9,7 @@ import ctypes as C
 RCC_ABI_VERSION = 1
 
 # status
-RCC_OK, RCC_ERR_ARG, RCC_ERR_UNSUPPORTED, RCC_ERR_DEVICE, RCC_ERR_CAPACITY, RCC_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+RCC_OK, RCC_ERR_ARG, RCC_ERR_UNSUPPORTED, RCC_ERR_DEVICE, RCC_ERR_CAPACITY, RCC_ERR_NOMEM, RCC_ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 # enums
 RCC_PIX_MONO8, RCC_PIX_BGR8 = 0, 1
 RCC_DIST_NONE, RCC_DIST_PLUMB_BOB, RCC_DIST_FISHEYE = 0, 1, 2

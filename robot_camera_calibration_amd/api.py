@@ -58,6 +58,10 @@ def load_library():
     L.rcc_destroy.argtypes = [P]
     L.rcc_destroy.restype = None
     L.rcc_detect_batch.argtypes = [P, P, I, I, P, C.POINTER(I), P, P]
+    L.rcc_detect_batch_submit.argtypes = [P, P, I, I, P, P]
+    L.rcc_detect_batch_submit.restype = C.c_int
+    L.rcc_detect_batch_collect.argtypes = [P, P, C.POINTER(I)]
+    L.rcc_detect_batch_collect.restype = C.c_int
     L.rcc_solve_pnp_batch.argtypes = [P, P, P, P, I, P, P, I, P, P, P, P, P]
     L.rcc_rodrigues_v2m_batch.argtypes = [P, P, I, P]
     L.rcc_rodrigues_m2v_batch.argtypes = [P, P, I, P]
@@ -102,7 +106,7 @@ EXPORTED_SYMBOLS = (
     "rcc_default_config", "rcc_create", "rcc_destroy", "rcc_status_string", "rcc_last_device_error",
     "rcc_abi_version", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
     "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_set_dense_variant",
-    "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_set_dense_skip", "rcc_set_keep_binary", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline", "rcc_time_copy", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
+    "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_set_dense_skip", "rcc_set_keep_binary", "rcc_set_fuse_grid_pnp", "rcc_detect_batch_submit", "rcc_detect_batch_collect", "rcc_set_pipeline", "rcc_time_copy", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
     "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch", "rcc_debug_calib_copy",
     "rcc_debug_pnp_probe",
 )
@@ -199,6 +203,28 @@ class Detector:
         st = self._L.rcc_detect_batch(self._h, _ptr(frames), nframes, mem, _ptr(det), C.byref(ndet),
                                       _ptr(fc), _ptr(stream))
         self._chk(st, "rcc_detect_batch")
+        return det[:ndet.value].view(np.recarray), (fc[:nframes].view(np.recarray) if fc is not None else None)
+
+    def submit(self, frames, nframes=None, want_corners=False, stream=None):
+        """Asynchronous detect(): launch a batch and return; at most two may be outstanding.  collect() hands back
+        the oldest one's results.  `frames` must stay alive (and unmodified) until that batch has been collected."""
+        if nframes is None:
+            nframes = int(frames.shape[0])
+        mem = abi.RCC_MEM_DEVICE if _is_device(frames) else abi.RCC_MEM_HOST
+        if mem == abi.RCC_MEM_HOST and isinstance(frames, np.ndarray):
+            frames = np.ascontiguousarray(frames)
+        fc = np.zeros(max(nframes, 1), FC_DT) if want_corners else None
+        self._chk(self._L.rcc_detect_batch_submit(self._h, _ptr(frames), nframes, mem, _ptr(fc), _ptr(stream)), "rcc_detect_batch_submit")
+        if not hasattr(self, "_pending"):
+            self._pending = []
+        self._pending.append((frames, nframes, fc))
+
+    def collect(self):
+        """results of the oldest outstanding submit(): (detections, frame_corners or None), as detect() returns them"""
+        frames, nframes, fc = self._pending.pop(0)
+        det = np.zeros(max(nframes * self.cfg.max_targets, 1), DET_DT)
+        ndet = C.c_int32(0)
+        self._chk(self._L.rcc_detect_batch_collect(self._h, _ptr(det), C.byref(ndet)), "rcc_detect_batch_collect")
         return det[:ndet.value].view(np.recarray), (fc[:nframes].view(np.recarray) if fc is not None else None)
 
     def solve_pnp(self, obj_pts, img_pts, K=None, D=None, dist_model=None):

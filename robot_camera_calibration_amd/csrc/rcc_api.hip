@@ -38,6 +38,7 @@ const char* rcc_status_string(int s)
     case RCC_ERR_DEVICE: return "HIP device error";
     case RCC_ERR_CAPACITY: return "batch exceeds handle capacity";
     case RCC_ERR_NOMEM: return "out of memory";
+    case RCC_ERR_STATE: return "call out of order (submit / collect)";
     default: return "unknown status";
   }
 }
@@ -119,6 +120,9 @@ void rcc_destroy(rcc_handle* h)
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_det) (void)hipHostFree(h->h_det);
   if (h->h_ndet) (void)hipHostFree(h->h_ndet);
+  if (h->h_det2) (void)hipHostFree(h->h_det2);
+  if (h->h_ndet2) (void)hipHostFree(h->h_ndet2);
+  for (auto& e : h->sub_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   for (auto& ps : h->pstream) if (ps) (void)hipStreamDestroy(ps);
@@ -183,7 +187,10 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   ALLOC(h->d_img_scratch, B * 2 * RCC_MAX_BOARD_CORNERS * sizeof(double));
   ALLOC(h->d_board_obj, 3 * RCC_MAX_BOARD_CORNERS * sizeof(double));
   if (hipHostMalloc((void**)&h->h_det, B * (size_t)cfg->max_targets * sizeof(rcc_detection)) != hipSuccess ||
-      hipHostMalloc((void**)&h->h_ndet, B * sizeof(int32_t)) != hipSuccess) { rcc_destroy(h); return RCC_ERR_NOMEM; }
+      hipHostMalloc((void**)&h->h_ndet, B * sizeof(int32_t)) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_det2, B * (size_t)cfg->max_targets * sizeof(rcc_detection)) != hipSuccess ||
+      hipHostMalloc((void**)&h->h_ndet2, B * sizeof(int32_t)) != hipSuccess) { rcc_destroy(h); return RCC_ERR_NOMEM; }
+  for (auto& e : h->sub_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   {
     // object points of the board: index = row*cols + col, x right, y up, z = 0, origin at the
     // centre -- the object-frame convention of camera_pose.cpp:158-161
@@ -401,6 +408,7 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
   if (nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
   if (ndet) *ndet = 0;
   if (nframes == 0) return RCC_OK;
+  if (h->sub_head != h->sub_tail) return RCC_ERR_STATE;              // submissions outstanding: collect them first
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const uint8_t* d_frames = (const uint8_t*)frames;
@@ -460,6 +468,79 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
   if (r != RCC_OK) return r;
   (void)hipEventElapsedTime(&h->last_ms[0], h->ev[0], h->ev[1]);
   (void)hipEventElapsedTime(&h->last_ms[1], h->ev[1], h->ev[2]);
+  return RCC_OK;
+}
+
+// ---- asynchronous form: submit batch k+1 before collecting batch k -----------------------------------------------
+int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, int32_t frames_mem,
+                            rcc_frame_corners* corners, void* stream)
+{
+  if (!h || !frames || nframes < 1) return RCC_ERR_ARG;
+  if (frames_mem != RCC_MEM_HOST && frames_mem != RCC_MEM_DEVICE) return RCC_ERR_ARG;
+  if (nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
+  if (h->sub_head - h->sub_tail >= 2) return RCC_ERR_STATE;          // both result slots are in flight
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const int slot = (int)(h->sub_head & 1u);
+  const uint8_t* d_frames = (const uint8_t*)frames;
+  if (frames_mem == RCC_MEM_HOST) {
+    size_t need = (size_t)h->cfg.frame_bytes * nframes;
+    if (need > h->stage_bytes) {
+      if (h->sub_head != h->sub_tail) return RCC_ERR_STATE;          // cannot re-allocate the staging buffer under a batch in flight
+      if (h->d_stage) (void)hipFree(h->d_stage);
+      h->d_stage = nullptr;
+      h->stage_bytes = 0;
+      size_t cap = (size_t)h->cfg.frame_bytes * h->cfg.batch_capacity;
+      if (hipMalloc((void**)&h->d_stage, cap) != hipSuccess) return RCC_ERR_NOMEM;
+      h->stage_bytes = cap;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_stage, frames, need, hipMemcpyHostToDevice, s));
+    d_frames = h->d_stage;
+  }
+  const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
+  const int slots = h->cfg.max_targets;
+  HIPCHK(h, rcc_launch_ingest(h, d_frames, nframes, h->d_grey, s));
+  h->want_thr = h->keep_bin ? 0 : 1;
+  HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
+  h->want_thr = 0;
+  int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, false);
+  if (r != RCC_OK) return r;
+  rcc_detection* hd = slot ? h->h_det2 : h->h_det;
+  int32_t* hn = slot ? h->h_ndet2 : h->h_ndet;
+  HIPCHK(h, hipMemcpyAsync(hd, h->d_det, sizeof(rcc_detection) * (size_t)nframes * (fid ? slots : 1), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemcpyAsync(hn, h->d_ndet, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost, s));
+  if (corners) HIPCHK(h, hipMemcpyAsync(corners, h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipEventRecord(h->sub_ev[slot], s));
+  h->sub_nframes[slot] = nframes;
+  h->sub_stream[slot] = s;
+  ++h->sub_head;
+  for (float& m : h->last_ms) m = -1.0f;
+  return RCC_OK;
+}
+
+int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet)
+{
+  if (!h) return RCC_ERR_ARG;
+  if (ndet) *ndet = 0;
+  if (h->sub_head == h->sub_tail) return RCC_ERR_STATE;              // nothing submitted
+  HIPCHK(h, hipSetDevice(h->device));
+  const int slot = (int)(h->sub_tail & 1u);
+  HIPCHK(h, hipEventSynchronize(h->sub_ev[slot]));
+  const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
+  const int slots = h->cfg.max_targets, nframes = h->sub_nframes[slot];
+  const rcc_detection* hd = slot ? h->h_det2 : h->h_det;
+  const int32_t* hn = slot ? h->h_ndet2 : h->h_ndet;
+  int n = 0;
+  for (int f = 0; f < nframes; ++f) {
+    const int k = hn[f] < slots ? hn[f] : slots;
+    for (int q = 0; q < k; ++q) {
+      if (det) { det[n] = hd[(size_t)f * (fid ? slots : 1) + q]; det[n].frame = f; }
+      ++n;
+    }
+  }
+  if (ndet) *ndet = n;
+  h->sub_nframes[slot] = 0;
+  ++h->sub_tail;
   return RCC_OK;
 }
 

@@ -61,6 +61,14 @@ struct rcc_handle {
   size_t pnp_buf_bytes;
   rcc_detection* h_det;     // pinned
   int32_t* h_ndet;          // pinned
+  // rcc_detect_batch_submit / _collect: a second pinned result slot, so that the host can unpack batch k while the
+  // device runs batch k+1 (slot 0 = h_det / h_ndet above)
+  rcc_detection* h_det2;
+  int32_t* h_ndet2;
+  hipEvent_t sub_ev[2];     // results of the submission in slot i are in pinned memory
+  int sub_nframes[2];       // frames of the submission in slot i (0: slot free)
+  hipStream_t sub_stream[2];
+  unsigned sub_head, sub_tail;   // submissions issued / collected
   double* d_board_obj;      // 256 x 3 object points of the board
   double* d_img_scratch;    // B x 256 x 2 image points handed to the solver
   hipEvent_t ev[8];

@@ -353,6 +353,37 @@ def test_fused_grid_pnp_identical(torch_cuda):
     det.close()
 
 
+def test_submit_collect_stream(torch_cuda):
+    """rcc_detect_batch_submit / _collect: two batches in flight come back in order with the records detect() gives;
+    calls out of order return RCC_ERR_STATE"""
+    torch = torch_cuda
+    n = 24
+    cfg = _make(w=640, h=480, B=n)
+    det = api.Detector(cfg)
+    fa, _ = _render(torch, det, cfg, n, seed=11)
+    fb, _ = _render(torch, det, cfg, n, seed=12)
+    torch.cuda.synchronize()
+    da, ca = det.detect(fa, n)
+    db, cb = det.detect(fb, n)
+    with pytest.raises(api.RccError):
+        det.collect() if hasattr(det, "_pending") and det._pending else det._chk(det._L.rcc_detect_batch_collect(det._h, None, None), "collect")
+    det.submit(fa, n, want_corners=True)
+    det.submit(fb, n, want_corners=True)
+    with pytest.raises(api.RccError):
+        det._chk(det._L.rcc_detect_batch_submit(det._h, api._ptr(fa), n, abi.RCC_MEM_DEVICE, None, None), "third submit")
+    with pytest.raises(api.RccError):
+        det.detect(fa, n)                                   # the synchronous call refuses while batches are outstanding
+    ra, rca = det.collect()
+    det.submit(fa, n)                                       # slot reuse
+    rb, rcb = det.collect()
+    ra2, _ = det.collect()
+    assert ra.tobytes() == da.tobytes() and rb.tobytes() == db.tobytes() and ra2.tobytes() == da.tobytes()
+    assert rca.tobytes() == ca.tobytes() and rcb.tobytes() == cb.tobytes()
+    d_again, _ = det.detect(fb, n)
+    assert d_again.tobytes() == db.tobytes()
+    det.close()
+
+
 def test_pipeline_chunks_identical(torch_cuda):
     """rcc_set_pipeline: the chunked two-stream form of detect() returns the records of the single pass"""
     torch = torch_cuda
