@@ -20,18 +20,19 @@
 //     of the strip kernel does, reading its dwords from the ring at the window's (unaligned) offset;
 //   * threshold dwords go to an LDS row buffer; one iteration later wave j stores columns [256 j, 256 j + 256)
 //     of the four rows with one dwordx4 store (quarter-wave per row).
-// Synchronisation: one s_barrier per tile row.  Ring of 6 slots, DMA three tile rows ahead; the wait before the
-// barrier is a COUNTED s_waitcnt vmcnt(5): every wave issues at least one DMA and exactly one store per iteration
-// (both unconditional -- masked lanes / rows get an out-of-range buffer offset, which the hardware drops), so the
-// DMA of tile row t has at least 5 younger operations when it is waited for (the first three tile rows are
-// waited for outright in the prologue).  (hipcc is kept out of this
-// bookkeeping: the DMA is inline asm, since for the builtin it drains vmcnt(0) before every LDS read.)
+// Synchronisation: one s_barrier per tile row.  Ring of BAND_DEPTH + 3 slots, DMA BAND_DEPTH = 2 tile rows ahead
+// (1, 2 and 3 measure the same: the kernel is VALU-bound); the wait before the barrier is a COUNTED
+// s_waitcnt vmcnt(2 * BAND_DEPTH - 1): every wave issues at least one DMA and exactly one store per iteration (both
+// unconditional -- masked lanes / rows get an out-of-range buffer offset, which the hardware drops), so the DMA of
+// tile row t has at least 2 * BAND_DEPTH - 1 younger operations when it is waited for (the first tile rows are
+// waited for outright in the prologue).  hipcc is kept out of this bookkeeping: the DMA is inline asm, since for
+// the builtin it drains vmcnt(0) before every LDS read.
 #include "dense_rows.h"
 
 #define BAND_WAVES 8
 #define BAND_W RCC_BAND_W
 #ifndef BAND_DEPTH
-#define BAND_DEPTH 3          // tile rows of DMA in flight ahead of the front stage
+#define BAND_DEPTH 2          // tile rows of DMA in flight ahead of the front stage
 #endif
 #define BAND_RING (BAND_DEPTH + 3)   // + the row being read by the front, and the two behind it the back stage reads
 #define BAND_OPITCH 2048
@@ -239,8 +240,9 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
 #define BAND_PASS grey, w, h, nbands, nseg, seg_tiles, nframes, min_contrast, hthresh, margin, cap, allow_skip, bin, cand, cand_count
 template <int MODE, int PRIO, int NCH>
 __global__ __launch_bounds__(512) void k_dense_band(BAND_ARGS) { dense_band_body<MODE, PRIO, NCH>(BAND_PASS); }
-// the compact-map form with an 8-chunk ring needs 50 KB of LDS: three workgroups per CU fit if the kernel stays
-// within 80 VGPRs (6 waves per SIMD); measured 1.26 -> 1.18 ms per 1024 frames with the cap (6 dwords spill)
+// the compact-map form needs 42-47 KB of LDS: three workgroups per CU fit if the kernel stays within 80 VGPRs
+// (6 waves per SIMD); measured 1.26 -> 1.18 ms per 1024 x 1080p and 1.44 -> 1.32 ms per 256 x 4K with the cap (6-8
+// dwords spill)
 template <int MODE, int PRIO, int NCH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_dense_band_occ6(BAND_ARGS) { dense_band_body<MODE, PRIO, NCH>(BAND_PASS); }
 
@@ -260,7 +262,7 @@ static void launch_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8
 {
   const rcc_config& c = h->cfg;
   const long long njobs = (long long)nbands * nseg * nframes;
-  if constexpr (MODE == 2 && NCH == 8)
+  if constexpr (MODE == 2)
     hipLaunchKernelGGL((k_dense_band_occ6<MODE, PRIO, NCH>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nseg, seg_tiles,
                        nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count);
   else
