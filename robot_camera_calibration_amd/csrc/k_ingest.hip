@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void k_ingest_gather(const uint8_t* __restrict
 #define ST_PITCH 256          // grey bytes per LDS row (>= aligned box width)
 #define ST_ROWS 24            // LDS rows per buffer
 #define ST_MAXG ((ST_PITCH / 16) * ST_ROWS)
+#define ST_SLOTS 3            // 4-pixel source units per thread (box of up to 768 units = 3072 source pixels)
 
 // 16 BGR pixels (48 B in three 16-B registers) -> 16 grey bytes.  grey = (1868 B + 9617 G + 4899 R + 8192) >> 14
 // evaluated exactly with byte dot products: each weight w = 64*(w >> 6) + (w & 63), so
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   const int gw = (spanx < 100000) ? (((mxx + 1) - bxa) / 16 + 1) : (1 << 20);
   const int bh = (spany < 100000) ? (mxy + 1 - mny + 1) : (1 << 20);
   const int by0 = mny;
-  const bool fits = (gw * 16 <= ST_PITCH) && (bh <= ST_ROWS) && (gw * bh <= 256);   // block-uniform
+  const bool fits = (gw * 16 <= ST_PITCH) && (bh <= ST_ROWS) && (gw * 4 * bh <= 256 * ST_SLOTS);   // block-uniform
 
   if (!fits) {
     // gather path for this tile (same arithmetic, taps from global memory)
@@ -286,18 +287,24 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
     return;
   }
 
-  // one 16-pixel group per thread: wave v takes box rows v, v+4, ...; consecutive lanes take
-  // consecutive groups of a row (coalesced 48 B per lane), so all four SIMDs share the load/convert work
-  // groups are dealt out linearly over the block's threads (the box has gw*bh <= 256 groups, typically ~140, so
-  // only the first waves convert); the starting wave rotates with the tile so that the four SIMDs of a CU share
-  // this work across the resident blocks
-  const int gidx = (tid + 64 * (tile & 3)) & 255;
-  const int grow = gidx / gw, gcol = gidx - grow * gw;
-  const bool gact = grow < bh;
-  const int gsx = bxa + 16 * gcol, gsy = by0 + grow;
-  const bool gin = gact && gsx >= 0 && gsx < w && gsy >= 0 && gsy < h;
-  const size_t goff = gin ? ((size_t)gsy * stride + (size_t)gsx * NCH) : 0;
-  const int glds = grow * ST_PITCH + 16 * gcol;
+  // The source box is dealt out in 4-pixel units (12 B of BGR = one grey dword) over ALL threads of the block,
+  // unit u = tid + 256 * slot: every wave loads and converts its share (typically 1.5 units per thread), so the
+  // conversion no longer sits on the one or two waves that would own whole 16-pixel groups -- the block's waves
+  // reach the barrier together.
+  const int upr = gw * 4;                              // units per box row
+  const int nunits = upr * bh;
+  int uoff[ST_SLOTS], ulds[ST_SLOTS];
+  bool uact[ST_SLOTS], uin[ST_SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < ST_SLOTS; ++sl) {
+    const int u = tid + 256 * sl;
+    const int ur = u / upr, uc = u - ur * upr;
+    uact[sl] = u < nunits;
+    const int sx = bxa + 4 * uc, sy = by0 + ur;
+    uin[sl] = uact[sl] && sx >= 0 && sx < w && sy >= 0 && sy < h;
+    uoff[sl] = min(max(sy, 0), h - 1) * stride + min(max(sx, 0), w - 4) * NCH;     // clamped: always a valid address
+    ulds[sl] = uact[sl] ? ur * ST_PITCH + 4 * uc : ST_ROWS * ST_PITCH;             // idle units write the dump slot
+  }
   // per destination pixel: LDS dword address of the tap pair, byte shift, and the bilinear weights
   // in the form the byte dot product takes them
   int taddr[4], tsh[4], wx[4], wy0[4], wy1[4];
@@ -313,35 +320,33 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   }
 
   // Straight-line frame loop (the variant requires width % 128 == 0 and height % 8 == 0, so every
-  // thread owns 4 destination pixels): loads are unconditional -- an out-of-image group reads a
-  // clamped in-image address and is zeroed by a select (BORDER_CONSTANT 0), an idle lane re-reads
-  // group 0 -- so the compiler can count vmcnt instead of draining it.
-  struct Regs { uint4 a, b, d; };
-  const size_t goff_c = gin ? goff : ((size_t)min(max(gsy, 0), h - 1) * stride + (size_t)min(max(gsx, 0), w - 16) * NCH);
-  const bool wave_has = __any(gact);                 // wave-uniform: does this wave convert anything?
-  // buffer addressing: a per-frame descriptor (scalar arithmetic) + this thread's constant 32-bit offset; pointer
-  // arithmetic would cost a 64-bit multiply-add per access on the vector ALU
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  const int goff32 = (int)goff_c;
+  // thread owns 4 destination pixels): loads are unconditional within an active slot -- an out-of-image unit reads
+  // a clamped in-image address and is zeroed by a select (BORDER_CONSTANT 0) -- so the compiler can count vmcnt
+  // instead of draining it.  Buffer addressing: a per-frame descriptor (scalar arithmetic) + the thread's constant
+  // 32-bit offsets.
+  typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
+  struct Regs { u32x3_t q[ST_SLOTS]; };
+  bool slot_any[ST_SLOTS];
+#pragma unroll
+  for (int sl = 0; sl < ST_SLOTS; ++sl) slot_any[sl] = __any(uact[sl]);     // wave-uniform
   auto issue = [&](int f, Regs& r) {
-    if (!wave_has) return;
     const int fc = min(f, f1 - 1);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frames + (size_t)fc * frame_bytes), 0, (int)frame_bytes, 0x00020000);
-    const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rs, goff32, 0, 0);
-    r.a = make_uint4(a.x, a.y, a.z, a.w);
-    if (NCH == 3) {
-      const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rs, goff32 + 16, 0, 0);
-      const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(rs, goff32 + 32, 0, 0);
-      r.b = make_uint4(b.x, b.y, b.z, b.w);
-      r.d = make_uint4(d.x, d.y, d.z, d.w);
+#pragma unroll
+    for (int sl = 0; sl < ST_SLOTS; ++sl) {
+      if (!slot_any[sl]) continue;
+      if (NCH == 3) r.q[sl] = __builtin_amdgcn_raw_buffer_load_b96(rs, uoff[sl], 0, 0);
+      else r.q[sl].x = __builtin_amdgcn_raw_buffer_load_b32(rs, uoff[sl], 0, 0);
     }
   };
-  const int glds_c = gact ? glds : (ST_ROWS * ST_PITCH);          // idle lanes write a dump slot past the box
   auto commit = [&](uint8_t* buf, const Regs& r) {
-    if (!wave_has) return;
-    uint4 gq = (NCH == 3) ? rcc_grey16(r.a, r.b, r.d) : r.a;
-    if (!gin) gq = make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4*>(buf + glds_c) = gq;
+#pragma unroll
+    for (int sl = 0; sl < ST_SLOTS; ++sl) {
+      if (!slot_any[sl]) continue;
+      uint32_t g4 = (NCH == 3) ? rcc_grey4(r.q[sl].x, r.q[sl].y, r.q[sl].z) : r.q[sl].x;
+      if (!uin[sl]) g4 = 0;
+      *reinterpret_cast<uint32_t*>(buf + ulds[sl]) = g4;
+    }
   };
   const int out_off = y * w + x0;
   auto taps = [&](int f, const uint8_t* L) {
