@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   bool uact[ST_SLOTS], uin[ST_SLOTS];
 #pragma unroll
   for (int sl = 0; sl < ST_SLOTS; ++sl) {
-    const int u = tid + 256 * sl;
+    const int u = ((tid + 64 * (tile & 3)) & 255) + 256 * sl;     // the waves that get the partly filled last slot rotate with the tile
     const int ur = u / upr, uc = u - ur * upr;
     uact[sl] = u < nunits;
     const int sx = bxa + 4 * uc, sy = by0 + ur;
