@@ -143,6 +143,28 @@ def test_pipeline_config_variations(torch_cuda, oracle, mod):
     _check_batch(torch_cuda, oracle, cfg, frames, 3, expect_found=False)
 
 
+@pytest.mark.parametrize("noise,contrast,seed", [(0.0, (20, 235), 101), (2.0, (20, 235), 102), (6.0, (20, 235), 103),
+                                                 (3.0, (70, 170), 104), (10.0, (40, 210), 105)])
+def test_randomized_sweep_against_oracle(torch_cuda, oracle, noise, contrast, seed):
+    """64 random poses per setting (noise-free, nominal, noisy, low contrast, very noisy): every stage of every
+    frame against the oracle -- found or not, the two must agree"""
+    torch = torch_cuda
+    n = 64
+    cfg = _make(B=n)
+    det = api.Detector(cfg)
+    sp = abi.default_synth_params(seed=seed, noise=noise)
+    sp.black, sp.white = contrast
+    poses = synth.sample_poses(n, cfg, seed=seed)
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    torch.cuda.synchronize()
+    det.close()
+    mx, found = _check_batch(torch, oracle, cfg, frames, n, expect_found=False)
+    print("noise", noise, "contrast", contrast, "found", found, "of", n, mx)
+    if noise <= 2.0 and contrast == (20, 235):
+        assert found >= n - 2
+
+
 @pytest.mark.parametrize("w,h", [(645, 483), (322, 241), (64, 32), (67, 35), (131, 70)])
 def test_image_stages_ragged_noise(torch_cuda, oracle, w, h):
     """integer stages on noise + blobs at sizes that are not multiples of the tile: bit-exact"""
