@@ -630,6 +630,44 @@ int rcc_time_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes,
   return RCC_OK;
 }
 
+// experiment: do the ingest pass (bandwidth-bound) and the threshold+corner pass (issue-bound) overlap when they are
+// launched on two streams over independent buffers?  mode 0: back to back on one stream; 1: concurrently.
+int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,
+                      void* d_cand, void* d_cand_count, int32_t mode, int32_t reps, float* mean_ms)
+{
+  if (!h || !d_frames || !d_grey_out || !d_grey_in || !d_cand || !d_cand_count || nframes < 1 || reps < 1 || !mean_ms) return RCC_ERR_ARG;
+  if (nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = h->stream, a = h->pstream[0], b = h->pstream[1];
+  HIPCHK(h, hipStreamSynchronize(s));
+  HIPCHK(h, hipEventRecord(h->ev[6], s));
+  for (int r = 0; r < reps; ++r) {
+    if (mode == 0) {
+      HIPCHK(h, rcc_launch_ingest(h, (const uint8_t*)d_frames, nframes, (uint8_t*)d_grey_out, s));
+      h->want_thr = 1;
+      HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey_in, nframes, h->d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, s));
+    } else {
+      HIPCHK(h, hipEventRecord(h->pev[0], s));
+      HIPCHK(h, hipStreamWaitEvent(a, h->pev[0], 0));
+      HIPCHK(h, hipStreamWaitEvent(b, h->pev[0], 0));
+      HIPCHK(h, rcc_launch_ingest(h, (const uint8_t*)d_frames, nframes, (uint8_t*)d_grey_out, a));
+      h->want_thr = 1;
+      HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey_in, nframes, h->d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, b));
+      HIPCHK(h, hipEventRecord(h->pev[1], a));
+      HIPCHK(h, hipEventRecord(h->pev[2], b));
+      HIPCHK(h, hipStreamWaitEvent(s, h->pev[1], 0));
+      HIPCHK(h, hipStreamWaitEvent(s, h->pev[2], 0));
+    }
+  }
+  h->want_thr = 0;
+  HIPCHK(h, hipEventRecord(h->ev[7], s));
+  HIPCHK(h, hipEventSynchronize(h->ev[7]));
+  float ms = 0.0f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
+  *mean_ms = ms / (float)reps;
+  return RCC_OK;
+}
+
 // ---- solvePnP / Rodrigues drop-ins -----------------------------------------------------------------
 static int ensure_pnp_buf(rcc_handle* h, size_t bytes)
 {
