@@ -272,6 +272,11 @@ int rcc_debug_fetch_lists(rcc_handle* h, int32_t nframes, void* pre, int32_t* np
 int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin, void* cand,
                            int32_t* cand_count);
 
+/* experiment (scratch/t_overlap.py): the ingest pass and the threshold+corner pass over independent buffers, back to
+ * back on one stream (mode 0) or launched together on two streams (mode 1); mean milliseconds per pair. */
+int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,
+                      void* d_cand, void* d_cand_count, int32_t mode, int32_t reps, float* mean_ms);
+
 /* measurement aid: mean milliseconds of `reps` plain streaming copies (16 B per lane) of nbytes between two device
  * buffers (16-byte aligned, nbytes a multiple of 16), timed with HIP events on the handle's stream.  bench.py
  * quotes it beside the threshold+corner pass, which moves the same bytes. */

@@ -106,7 +106,7 @@ EXPORTED_SYMBOLS = (
     "rcc_default_config", "rcc_create", "rcc_destroy", "rcc_status_string", "rcc_last_device_error",
     "rcc_abi_version", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
     "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_set_dense_variant",
-    "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_set_dense_skip", "rcc_set_keep_binary", "rcc_set_fuse_grid_pnp", "rcc_detect_batch_submit", "rcc_detect_batch_collect", "rcc_set_pipeline", "rcc_time_copy", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
+    "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_set_dense_skip", "rcc_set_keep_binary", "rcc_set_fuse_grid_pnp", "rcc_detect_batch_submit", "rcc_detect_batch_collect", "rcc_debug_overlap", "rcc_set_pipeline", "rcc_time_copy", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
     "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch", "rcc_debug_calib_copy",
     "rcc_debug_pnp_probe",
 )
