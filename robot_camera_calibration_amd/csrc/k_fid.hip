@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
                                                    int32_t* __restrict__ ndet)
 {
   __shared__ int16_t s_px[FID_MAXN], s_py[FID_MAXN], s_nxt[FID_MAXN];
+  __shared__ int16_t s_cy[FID_MAXN];       // integer candidate row (the list stage's sort key): monotone, unlike the refined row
   __shared__ int8_t s_dx[FID_MAXN], s_dy[FID_MAXN];
   __shared__ uint8_t s_ok[FID_MAXN], s_thr[FID_MAXN], s_hitf[FID_MAXN];
   __shared__ fid_hit s_hit[FID_MAXN];
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
     const int x = (int)floor(xy[2 * i] + 0.5), y = (int)floor(xy[2 * i + 1] + 0.5);
     int dx = 0, dy = 0, t = 0;
     const bool ok = fid_corner_class(g, w, h, x, y, min_contrast, dx, dy, t);
+    s_cy[i] = pre[(size_t)f * kstride + i].y;
     s_px[i] = (int16_t)x; s_py[i] = (int16_t)y; s_ok[i] = ok; s_dx[i] = (int8_t)dx; s_dy[i] = (int8_t)dy; s_thr[i] = (uint8_t)t;
     s_hitf[i] = 0;
   }
@@ -251,8 +253,24 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
     int cj[FK], cw[FK], npass = 0;
 #pragma unroll
     for (int q = 0; q < FK; ++q) { cj[q] = -1; cw[q] = 0x7FFFFFFF; }
+    // Half of the list is enough when the direction is steeper than the cone is wide (8 dy^2 > |d|^2: the cone's
+    // half-angle has sin^2 = 1/8): every point of the cone then lies strictly on dy's side of this corner's row.  The
+    // list is sorted by the integer candidate row, which differs from the refined, rounded row by at most 8
+    // (k_subpix rejects moves beyond its window, <= 7), hence the slack of 16 rows.
+    int lo = 0, hi = nc;
+    if (act && 8 * dy * dy > dd) {
+      const int yc = s_cy[i];
+      int a0 = 0, a1 = nc;
+      if (dy > 0) {
+        while (a0 < a1) { const int m = (a0 + a1) >> 1; if (s_cy[s_cidx[m]] < yc - 16) a0 = m + 1; else a1 = m; }
+        lo = a0;
+      } else {
+        while (a0 < a1) { const int m = (a0 + a1) >> 1; if (s_cy[s_cidx[m]] <= yc + 16) a0 = m + 1; else a1 = m; }
+        hi = a0;
+      }
+    }
     if (act) {
-      for (int cjx = 0; cjx < nc; ++cjx) {
+      for (int cjx = lo; cjx < hi; ++cjx) {
         const int j = s_cidx[cjx];
         const int wx = s_px[j] - xi, wy = s_py[j] - yi;
         const int ww = wx * wx + wy * wy;                    // <= 2 * 16384^2 fits int32
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
     }
     if (act && best < 0 && npass > FK) {
       int bestd = 0;
-      for (int cjx = 0; cjx < nc; ++cjx) {
+      for (int cjx = lo; cjx < hi; ++cjx) {
         const int j = s_cidx[cjx];
         if (j == i) continue;
         const int wx = s_px[j] - xi, wy = s_py[j] - yi;
