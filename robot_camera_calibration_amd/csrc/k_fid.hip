@@ -186,7 +186,92 @@ __device__ bool fid_decode(const uint8_t* __restrict__ g, int w, int h, const do
   return true;
 }
 
-struct fid_hit { int16_t j, k, l, pad; int32_t id; int16_t ham, rot; };
+// The same decode by the G lanes of a group (G | 64, lanes lg = 0..G-1 of one quad all call this with the same q; the
+// control flow is wave-uniform, so groups without a quad pass valid = false and come back with false).  fid_decode above is
+// the plain statement (one lane: ~100 dependent sample loads, a 64-entry scratch array and 4 * ncodes popcounts on a single
+// lane made it 0.2-0.4 ms of the kernel); here every lane takes 100 / G samples and ncodes / G code words, the three
+// decisions (all samples inside, contrast, border) and the best (hamming, rotation, id) are reduced over the group.
+// Same operations per sample and per code word, hence the same result.
+struct fid_hit { int16_t id; int8_t ham, rot; };      // id < 0: none
+struct fid_lane { unsigned long long best; uint32_t pk, ddt; };
+#define FID_QCAP 512                                   // pairs per wave: 64 lanes x 8 scan steps; 4 waves x 512 x 4 B = the s_hit array
+static_assert(sizeof(fid_hit) == 4 && FID_MAXN * sizeof(fid_hit) >= 4 * FID_QCAP * sizeof(uint32_t), "pair queue aliases s_hit");
+static_assert(FID_MAXN <= 2048, "11-bit compact corner index in the pair queue and the link key");
+
+template <int G>
+__device__ __forceinline__ int fid_gsum(int v) { for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, G); return v; }
+template <int G>
+__device__ __forceinline__ unsigned fid_gor(unsigned v) { for (int o = G >> 1; o > 0; o >>= 1) v |= (unsigned)__shfl_xor((int)v, o, G); return v; }
+template <int G>
+__device__ __forceinline__ unsigned fid_gmin(unsigned v) { for (int o = G >> 1; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o, G)); return v; }
+
+template <int G>
+__device__ bool fid_decode_group(const uint8_t* __restrict__ g, int w, int h, const double q[8], const uint64_t* __restrict__ codes,
+                                 int ncodes, int max_hamming, int lg, bool valid, int& id, int& ham, int& rot)
+{
+  double H[9];
+  for (int k = 0; k < 9; ++k) H[k] = 0.0;
+  const bool hok = valid && fid_homography(q, H);
+  constexpr int NS = (100 + G - 1) / G;
+  int sv[NS];
+  int bsum = 0, wsum = 0;
+  unsigned fail = hok ? 0u : 1u;
+#pragma unroll
+  for (int m = 0; m < NS; ++m) {
+    const int s = lg + G * m;
+    const bool cellp = s < 64, use = s < 100;
+    double u, v;
+    if (cellp) { u = (double)(s & 7) + 0.5; v = (double)(s >> 3) + 0.5; }
+    else {
+      const int t = s - 64;                                 // the white ring: top 10, bottom 10, left 8, right 8
+      if (t < 10) { u = (double)(t - 1) + 0.5; v = -0.5; }
+      else if (t < 20) { u = (double)(t - 11) + 0.5; v = 8.5; }
+      else if (t < 28) { u = -0.5; v = (double)(t - 20) + 0.5; }
+      else { u = 8.5; v = (double)(t - 28) + 0.5; }
+    }
+    const int val = (use && hok) ? fid_sample(g, w, h, H, u, v) : 0;
+    if (val < 0) fail = 1u;
+    sv[m] = val;
+    const int r = s >> 3, c = s & 7;
+    if (cellp && (r == 0 || r == 7 || c == 0 || c == 7)) bsum += val;
+    if (!cellp && use) wsum += val;
+  }
+  bsum = fid_gsum<G>(bsum); wsum = fid_gsum<G>(wsum); fail = fid_gor<G>(fail);
+  const int black = bsum / 28, white = wsum / 36;
+  if (white - black < 40) fail = 1u;
+  const int thr = (black + white) / 2;
+  unsigned s_lo = 0, s_hi = 0, border_hi = 0;
+#pragma unroll
+  for (int m = 0; m < NS; ++m) {
+    const int s = lg + G * m;
+    if (s < 64) {
+      const int r = s >> 3, c = s & 7;
+      if (r == 0 || r == 7 || c == 0 || c == 7) { if (sv[m] >= thr) border_hi = 1u; }
+      else if (sv[m] > thr) {
+        const int b = 35 - ((r - 1) * 6 + (c - 1));
+        if (b < 32) s_lo |= 1u << b; else s_hi |= 1u << (b - 32);
+      }
+    }
+  }
+  s_lo = fid_gor<G>(s_lo); s_hi = fid_gor<G>(s_hi); border_hi = fid_gor<G>(border_hi);
+  if (border_hi) fail = 1u;
+  uint64_t M = ((uint64_t)s_hi << 32) | s_lo;
+  unsigned key = 0xFFFFFFFFu;                               // hamming * 4 ncodes + rotation * ncodes + id: the serial scan's order
+  const unsigned n4 = 4u * (unsigned)ncodes;
+  for (int rr = 0; rr < 4; ++rr) {
+    for (int k = lg; k < ncodes; k += G) {
+      const unsigned hd = (unsigned)__popcll(M ^ codes[k]);
+      key = min(key, hd * n4 + (unsigned)(rr * ncodes + k));
+    }
+    M = fid_rot36(M);
+  }
+  key = fid_gmin<G>(key);
+  if (fail || key == 0xFFFFFFFFu) return false;
+  const unsigned hd = key / n4, rem = key - hd * n4;
+  if ((int)hd > max_hamming) return false;
+  ham = (int)hd; rot = (int)(rem / (unsigned)ncodes); id = (int)(rem - (unsigned)rot * (unsigned)ncodes);
+  return true;
+}
 
 __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ grey, int w, int h, int min_contrast,
                                                    const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
@@ -196,14 +281,26 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
                                                    rcc_frame_corners* __restrict__ fc, rcc_detection* __restrict__ det,
                                                    int32_t* __restrict__ ndet)
 {
-  __shared__ int16_t s_px[FID_MAXN], s_py[FID_MAXN], s_nxt[FID_MAXN];
+  // per corner (index i of the kept list): successor, classification; per CLASSIFIED corner (compact index c, ascending
+  // in i): packed rounded position, candidate row, i.  s_pk / s_cy are written by i in phase 1 and compacted in place.
+  __shared__ __attribute__((aligned(16))) uint32_t s_pk[FID_MAXN];   // x | y << 16
   __shared__ int16_t s_cy[FID_MAXN];       // integer candidate row (the list stage's sort key): monotone, unlike the refined row
+  __shared__ int16_t s_nxt[FID_MAXN];
   __shared__ int8_t s_dx[FID_MAXN], s_dy[FID_MAXN];
-  __shared__ uint8_t s_ok[FID_MAXN], s_thr[FID_MAXN], s_hitf[FID_MAXN];
-  __shared__ fid_hit s_hit[FID_MAXN];
-  __shared__ int16_t s_cidx[FID_MAXN];     // indices of the convex black corners, ascending
-  __shared__ int s_nc;
+  __shared__ uint8_t s_ok[FID_MAXN], s_thr[FID_MAXN];
+  __shared__ fid_hit s_hit[FID_MAXN];      // by the cycle's smallest corner index
+  __shared__ int16_t s_cidx[FID_MAXN];     // i of compact corner c
+  __shared__ int16_t s_quad[FID_MAXN / 4]; // smallest corner index of every 4-cycle (a corner has one successor: <= n / 4 cycles)
+  __shared__ fid_lane s_lane[256];         // phase 2 (C): the lanes' corner and their best link so far
+  __shared__ int s_nc, s_nq;
   const int f = blockIdx.x, tid = threadIdx.x;
+#ifdef RCC_FID_TRACE
+  long long tk[8]; int tki = 0;
+#define FID_TICK() do { __syncthreads(); tk[tki++] = wall_clock64(); } while (0)
+#else
+#define FID_TICK() do {} while (0)
+#endif
+  FID_TICK();
   rcc_frame_corners* out = fc + f;
   if (out->status != 0) { if (tid == 0) ndet[f] = 0; return; }
   const uint8_t* g = grey + (size_t)f * w * h;
@@ -213,43 +310,60 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
   for (int i = tid; i < n; i += 256) {
     const int x = (int)floor(xy[2 * i] + 0.5), y = (int)floor(xy[2 * i + 1] + 0.5);
     int dx = 0, dy = 0, t = 0;
-    const bool ok = fid_corner_class(g, w, h, x, y, min_contrast, dx, dy, t);
+    const bool ok = fid_corner_class(g, w, h, x, y, min_contrast, dx, dy, t);   // ok implies 5 <= x < w - 5 < 65536 (same for y)
     s_cy[i] = pre[(size_t)f * kstride + i].y;
-    s_px[i] = (int16_t)x; s_py[i] = (int16_t)y; s_ok[i] = ok; s_dx[i] = (int8_t)dx; s_dy[i] = (int8_t)dy; s_thr[i] = (uint8_t)t;
-    s_hitf[i] = 0;
+    s_pk[i] = ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16);
+    s_ok[i] = ok; s_dx[i] = (int8_t)dx; s_dy[i] = (int8_t)dy; s_thr[i] = (uint8_t)t;
+    s_nxt[i] = -1;
   }
+  if (tid == 0) s_nq = 0;
   __syncthreads();
-  // ordered compaction of the classified corners: only they can be linked (typically a third of n),
-  // and ascending order keeps the specification's tie-break (nearest, then smallest index)
+  FID_TICK();
+  // ordered compaction of the classified corners: only they can be linked (typically a third of n), and ascending order
+  // keeps the specification's tie-break (nearest, then smallest index).  In place: compact index <= i, and a chunk's 64
+  // reads precede its writes (one wave, lockstep).
   if (tid < 64) {
     int base = 0;
     for (int c0 = 0; c0 < n; c0 += 64) {
       const int i = c0 + tid;
       const bool k = (i < n) && s_ok[i];
+      const uint32_t pk = (i < n) ? s_pk[i] : 0u;
+      const int16_t cy = (i < n) ? s_cy[i] : (int16_t)0;
       const unsigned long long bal = __ballot(k);
-      if (k) s_cidx[base + __popcll(bal & ((1ull << tid) - 1ull))] = (int16_t)i;
+      const int c = base + __popcll(bal & ((1ull << tid) - 1ull));
+      __builtin_amdgcn_wave_barrier();
+      if (k) { s_cidx[c] = (int16_t)i; s_pk[c] = pk; s_cy[c] = cy; }
       base += __popcll(bal);
     }
     if (tid == 0) s_nc = base;
   }
   __syncthreads();
   const int nc = s_nc;
-  // phase 2: link along d1 (black on the (-dy, dx) side of the direction of travel): nearest accepted
-  for (int i = tid; i < n; i += 256) s_nxt[i] = -1;
-  __syncthreads();
-  // The specification: among the corners j that pass the integer gates (distance, direction, cone) AND whose
-  // connecting segment verifies (fid_edge_ok), the nearest one, ties to the smallest index.  The verification
-  // reads 16 pixels; done inside the scan it ran whenever any lane of the wave had a candidate (a few memory
-  // latencies per scan step: 4 ms per batch).  So: (A) a pure-ALU scan keeps the FK nearest gate-passers in
-  // (distance, index) order; (B) they are verified in that order, all lanes in step; (C) only if all FK fail and
-  // more passed the gates, the plain scan finishes the job (rare; keeps the result exact).
+  FID_TICK();
+  // phase 2: link along d1 (black on the (-dy, dx) side of the direction of travel).  The specification: among the corners
+  // j that pass the integer gates (distance, direction, cone) AND whose connecting segment verifies (fid_edge_ok), the
+  // nearest one, ties to the smallest index.  The verification reads 16 pixels; done inside the scan it ran whenever any
+  // lane of the wave had a candidate (a memory latency per scan step).  So: (A) a pure-ALU scan over the packed compact
+  // positions (one 16-byte LDS read per 4 corners) keeps the FK nearest gate-passers in (distance, index) order; (B) they
+  // are probed together; (C) only if all FK fail and more passed the gates, the remaining passers are probed FK at a time.
   constexpr int FK = 4;
   for (int c0 = 0; c0 < nc; c0 += 256) {
     const int ci = c0 + tid;
     const bool act = ci < nc;
     const int i = act ? s_cidx[ci] : 0;
     const int dx = s_dx[i], dy = s_dy[i], dd = dx * dx + dy * dy;
-    const int xi = s_px[i], yi = s_py[i], t = s_thr[i];
+    const uint32_t pki = s_pk[act ? ci : 0];
+    const int xi = (int)(pki & 0xFFFFu), yi = (int)(pki >> 16), t = s_thr[i];
+    // gates of compact corner c at packed position e: squared distance, or -1 (|cross| < 2^21: its square needs 64 bits)
+    auto gate = [&](int c, uint32_t e, int& wx, int& wy) -> int {
+      wx = (int)(e & 0xFFFFu) - xi; wy = (int)(e >> 16) - yi;
+      const int ww = wx * wx + wy * wy;                      // <= 2 * 16384^2 (rcc_create limits the frame to 16384 x 16384)
+      const int cr = wx * dy - wy * dx;
+      const unsigned ac = (unsigned)abs(cr);
+      const bool pass = (c != ci) && (ww >= 64) && (wx * dx + wy * dy > 0) &&
+                        (8ull * ((unsigned long long)ac * ac) <= (unsigned long long)(unsigned)ww * (unsigned)dd);
+      return pass ? ww : -1;
+    };
     int cj[FK], cw[FK], npass = 0;
 #pragma unroll
     for (int q = 0; q < FK; ++q) { cj[q] = -1; cw[q] = 0x7FFFFFFF; }
@@ -257,29 +371,31 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
     // half-angle has sin^2 = 1/8): every point of the cone then lies strictly on dy's side of this corner's row.  The
     // list is sorted by the integer candidate row, which differs from the refined, rounded row by at most 8
     // (k_subpix rejects moves beyond its window, <= 7), hence the slack of 16 rows.
-    int lo = 0, hi = nc;
+    int lo = 0, hi = act ? nc : 0;
     if (act && 8 * dy * dy > dd) {
-      const int yc = s_cy[i];
+      const int yc = s_cy[ci];
       int a0 = 0, a1 = nc;
       if (dy > 0) {
-        while (a0 < a1) { const int m = (a0 + a1) >> 1; if (s_cy[s_cidx[m]] < yc - 16) a0 = m + 1; else a1 = m; }
+        while (a0 < a1) { const int m = (a0 + a1) >> 1; if (s_cy[m] < yc - 16) a0 = m + 1; else a1 = m; }
         lo = a0;
       } else {
-        while (a0 < a1) { const int m = (a0 + a1) >> 1; if (s_cy[s_cidx[m]] <= yc + 16) a0 = m + 1; else a1 = m; }
+        while (a0 < a1) { const int m = (a0 + a1) >> 1; if (s_cy[m] <= yc + 16) a0 = m + 1; else a1 = m; }
         hi = a0;
       }
     }
-    if (act) {
-      for (int cjx = lo; cjx < hi; ++cjx) {
-        const int j = s_cidx[cjx];
-        const int wx = s_px[j] - xi, wy = s_py[j] - yi;
-        const int ww = wx * wx + wy * wy;                    // <= 2 * 16384^2 fits int32
-        const long long cr = (long long)wx * dy - (long long)wy * dx;
-        const bool pass = (j != i) && (ww >= 64) && (wx * dx + wy * dy > 0) && (8 * cr * cr <= (long long)ww * dd);
-        if (pass) {
+    // (A)
+    for (int c4 = lo & ~3; c4 < hi; c4 += 4) {
+      const uint4 e4 = *reinterpret_cast<const uint4*>(&s_pk[c4]);
+      const uint32_t ev[4] = { e4.x, e4.y, e4.z, e4.w };
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c4 + u;
+        int wx, wy;
+        const int ww = gate(c, ev[u], wx, wy);
+        if (ww >= 0 && c >= lo && c < hi) {
           ++npass;
-          // insert (ww, j) into the ascending list; j ascends along the scan, so an equal ww goes after its equals
-          int jw = ww, jj = j;
+          // insert (ww, c) into the ascending list; c ascends along the scan, so an equal ww goes after its equals
+          int jw = ww, jj = c;
 #pragma unroll
           for (int q = 0; q < FK; ++q) {
             if (jw < cw[q]) { const int tw = cw[q], tj = cj[q]; cw[q] = jw; cj[q] = jj; jw = tw; jj = tj; }
@@ -287,35 +403,70 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
         }
       }
     }
-    int best = -1;
+    // (B) all FK probes are made unconditionally (an empty slot probes the corner against itself), so that the 16 FK loads
+    // are in flight together; the first good one in (distance, index) order is the link
+    bool okq[FK];
 #pragma unroll
     for (int q = 0; q < FK; ++q) {
-      if (act && best < 0 && cj[q] >= 0) {
-        const int j = cj[q];
-        if (fid_edge_ok(g, w, h, xi, yi, s_px[j] - xi, s_py[j] - yi, -dy, dx, t)) best = j;
-      }
+      const uint32_t e = cj[q] >= 0 ? s_pk[cj[q]] : pki;
+      okq[q] = fid_edge_ok(g, w, h, xi, yi, (int)(e & 0xFFFFu) - xi, (int)(e >> 16) - yi, -dy, dx, t);
     }
-    if (act && best < 0 && npass > FK) {
-      int bestd = 0;
-      for (int cjx = lo; cjx < hi; ++cjx) {
-        const int j = s_cidx[cjx];
-        if (j == i) continue;
-        const int wx = s_px[j] - xi, wy = s_py[j] - yi;
-        const int ww = wx * wx + wy * wy;
-        if (ww < 64) continue;
-        if (wx * dx + wy * dy <= 0) continue;
-        const long long cr = (long long)wx * dy - (long long)wy * dx;
-        if (8 * cr * cr > (long long)ww * dd) continue;
-        if (best >= 0 && ww >= bestd) continue;
-        if (!fid_edge_ok(g, w, h, xi, yi, wx, wy, -dy, dx, t)) continue;
-        best = j; bestd = ww;
+    int best = -1;
+#pragma unroll
+    for (int q = FK - 1; q >= 0; --q) if (act && cj[q] >= 0 && okq[q]) best = cj[q];
+    // (C) every remaining passer has to be probed (the nearest good one wins): corners of the code pattern pass the gates
+    // with 25-100 others and link to none.  Probing inside the scan cost a memory latency per scan step for the whole wave;
+    // probing FK at a time per lane left most lanes idle (the kernel is VALU-bound once enough frames are in flight).  So
+    // the wave re-scans 8 corners per lane at a time, queues the passing (lane, corner) pairs in LDS, and probes the
+    // queue with all 64 lanes; the nearest good corner per lane is an LDS atomic min of (distance, index).  A passer no
+    // nearer than the lane's best so far is not queued.
+    {
+      const int lane = tid & 63, wbase = tid & ~63;
+      uint32_t* const s_q = reinterpret_cast<uint32_t*>(s_hit) + (tid >> 6) * FID_QCAP;   // s_hit is idle until phase 3
+      fid_lane ln;
+      ln.best = ~0ull; ln.pk = pki; ln.ddt = ((uint32_t)dx & 0xFFu) | (((uint32_t)dy & 0xFFu) << 8) | ((uint32_t)t << 16);
+      s_lane[tid] = ln;
+      const bool need = act && best < 0 && npass > FK;
+      int pos = need ? lo : hi;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      while (__any(pos < hi)) {
+        const unsigned long long bk = s_lane[tid].best;
+        const int bestd = (bk == ~0ull) ? 0x7FFFFFFF : (int)(bk >> 11);
+        int qn = 0;
+        for (int st = 0; st < FID_QCAP / 64; ++st) {
+          const bool in = pos < hi;
+          const int c = in ? pos : 0;
+          int wx, wy;
+          const int ww = gate(c, s_pk[c], wx, wy);
+          const bool pass = in && ww >= 0 && ww < bestd;
+          const unsigned long long bal = __ballot(pass);
+          if (pass) s_q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)lane | ((uint32_t)c << 6);
+          qn += __popcll(bal);
+          pos += in ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int p = lane; p < qn; p += 64) {
+          const uint32_t pr = s_q[p];
+          const int L = (int)(pr & 63u), c = (int)(pr >> 6);
+          const uint32_t pkL = s_lane[wbase + L].pk, ddtL = s_lane[wbase + L].ddt, e = s_pk[c];
+          const int xL = (int)(pkL & 0xFFFFu), yL = (int)(pkL >> 16);
+          const int dxL = (int)(int8_t)(ddtL & 0xFFu), dyL = (int)(int8_t)((ddtL >> 8) & 0xFFu), tL = (int)(ddtL >> 16);
+          const int wx = (int)(e & 0xFFFFu) - xL, wy = (int)(e >> 16) - yL;
+          if (fid_edge_ok(g, w, h, xL, yL, wx, wy, -dyL, dxL, tL))
+            atomicMin(&s_lane[wbase + L].best, ((unsigned long long)(unsigned)(wx * wx + wy * wy) << 11) | (unsigned long long)c);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
+      const unsigned long long bk = s_lane[tid].best;
+      if (need && bk != ~0ull) best = (int)(bk & 2047ull);
     }
-    if (act) s_nxt[i] = (int16_t)best;
+    if (act && best >= 0) s_nxt[i] = s_cidx[best];
   }
   __syncthreads();
-  // phase 3: 4-cycles from their smallest index, decode
+  FID_TICK();
+  // phase 3: 4-cycles, listed by their smallest index
   for (int i = tid; i < n; i += 256) {
+    s_hit[i].id = -1;                      // (the array was the link phase's pair queue)
     if (!s_ok[i]) continue;
     const int j = s_nxt[i]; if (j < 0) continue;
     const int k = s_nxt[j]; if (k < 0) continue;
@@ -323,30 +474,45 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
     if (s_nxt[l] != i) continue;
     if (j == k || j == l || k == l || k == i || j == i || l == i) continue;
     if (!(i < j && i < k && i < l)) continue;
-    const int idx[4] = { i, j, k, l };
-    double q[8];
-    for (int c = 0; c < 4; ++c) { q[2 * c] = xy[2 * idx[c]]; q[2 * c + 1] = xy[2 * idx[c] + 1]; }
-    const double e1 = (q[2] - q[0]) * (q[5] - q[3]), e2 = (q[3] - q[1]) * (q[4] - q[2]);
-    const double cr = e1 - e2;
-    if (!(cr > 0.0)) continue;
-    int id, ham, rot;
-    if (!fid_decode(g, w, h, q, codes, ncodes, max_hamming, id, ham, rot)) continue;
-    fid_hit hrec;
-    hrec.j = (int16_t)j; hrec.k = (int16_t)k; hrec.l = (int16_t)l; hrec.pad = 0; hrec.id = id; hrec.ham = (int16_t)ham; hrec.rot = (int16_t)rot;
-    s_hit[i] = hrec;
-    s_hitf[i] = 1;
+    s_quad[atomicAdd(&s_nq, 1)] = (int16_t)i;
   }
   __syncthreads();
-  // ordered emission (by the cycle's smallest index, as the specification's scan does)
-  if (tid == 0) {
-    int m = 0;
-    for (int i = 0; i < n; ++i) {
-      if (!s_hitf[i]) continue;
-      if (m < max_targets) {
+  FID_TICK();
+  // decode: FID_G lanes per quad
+  {
+    constexpr int G = 16, NG = 256 / G;
+    const int nq = s_nq, gid = tid / G, lg = tid % G;
+    for (int qb = 0; qb < nq; qb += NG) {
+      const bool have = qb + gid < nq;
+      const int i = have ? s_quad[qb + gid] : 0;
+      int idx[4];
+      idx[0] = i;
+      for (int c = 1; c < 4; ++c) { const int nx = have ? s_nxt[idx[c - 1]] : 0; idx[c] = nx; }
+      double q[8];
+      for (int c = 0; c < 4; ++c) { q[2 * c] = have ? xy[2 * idx[c]] : 0.0; q[2 * c + 1] = have ? xy[2 * idx[c] + 1] : 0.0; }
+      const double e1 = (q[2] - q[0]) * (q[5] - q[3]), e2 = (q[3] - q[1]) * (q[4] - q[2]);
+      const double cr = e1 - e2;
+      int id = 0, ham = 0, rot = 0;
+      const bool hit = fid_decode_group<G>(g, w, h, q, codes, ncodes, max_hamming, lg, have && (cr > 0.0), id, ham, rot);
+      if (hit && lg == 0) { fid_hit hrec; hrec.id = (int16_t)id; hrec.ham = (int8_t)ham; hrec.rot = (int8_t)rot; s_hit[i] = hrec; }
+    }
+  }
+  __syncthreads();
+  FID_TICK();
+  // ordered emission (by the cycle's smallest index, as the specification's scan does): wave 0, one lane per hit
+  if (tid < 64) {
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int i = c0 + tid;
+      const bool hit = (i < n) && s_hit[i].id >= 0;
+      const unsigned long long bal = __ballot(hit);
+      const int m = base + __popcll(bal & ((1ull << tid) - 1ull));
+      if (hit && m < max_targets) {
         const fid_hit hrec = s_hit[i];
         rcc_detection d;
         d.frame = f; d.id = hrec.id; d.hamming = hrec.ham; d.ncorners = 4; d.size = tag_size;
-        const int idx[4] = { i, hrec.j, hrec.k, hrec.l };
+        int idx[4];
+        idx[0] = i; idx[1] = s_nxt[i]; idx[2] = s_nxt[idx[1]]; idx[3] = s_nxt[idx[2]];
         const int rot = hrec.rot;
         const int ord[4] = { (rot + 3) & 3, (rot + 2) & 3, (rot + 1) & 3, rot & 3 };   // bl, br, tr, tl
         for (int c = 0; c < 4; ++c) { d.corners[c][0] = xy[2 * idx[ord[c]]]; d.corners[c][1] = xy[2 * idx[ord[c]] + 1]; }
@@ -354,14 +520,22 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
         d.rms = 0.0; d.pnp_status = 0; d.pnp_iters = 0;
         det[(size_t)f * max_targets + m] = d;
       }
-      ++m;
+      base += __popcll(bal);
     }
-    const int kept = min(m, max_targets);
-    ndet[f] = kept;
-    out->nkept = n;
-    out->ncorners = 0;
-    if (kept == 0) out->status |= RCC_FRAME_NOT_FOUND;
+    if (tid == 0) {
+      const int kept = min(base, max_targets);
+      ndet[f] = kept;
+      out->nkept = n;
+      out->ncorners = 0;
+      if (kept == 0) out->status |= RCC_FRAME_NOT_FOUND;
+    }
   }
+#ifdef RCC_FID_TRACE
+  FID_TICK();
+  if (tid == 0 && (f & 63) == 0)
+    printf("fid f=%d n=%d nc=%d  class %lld  compact %lld  link %lld  cycles %lld  decode %lld  emit %lld (x10ns)\n", f, n, nc, tk[1] - tk[0], tk[2] - tk[1],
+           tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
+#endif
 }
 
 // a7 for the tags: one lane per detection (camera_pose.cpp:152-163: four corners bl,br,tr,tl,
