@@ -10,8 +10,9 @@
 // corner positions, and the fp64 homography solve is written one rounded operation per step
 // (-ffp-contract=off), so the outputs equal the oracle's bit for bit.
 //
-// One 256-thread block per frame: the work is O(n^2) pair gating over n <= 2048 refined corners
-// plus a handful of decodes -- latency-bound, never bandwidth-bound; frames are the parallel axis.
+// One 256-thread block per frame (39.9 KB of LDS: four blocks per CU): O(n^2) integer pair gating over the classified
+// corners, 16-pixel edge probes for the pairs that pass, a handful of decodes -- VALU-bound once ~1000 frames are
+// resident, never bandwidth-bound; frames are the parallel axis.  DESIGN.md section 5 has the history.
 #include "rcc_internal.h"
 #define RCC_PNP_NOINLINE 1
 #include "pnp_core.h"
@@ -137,63 +138,17 @@ __device__ uint64_t fid_rot36(uint64_t c)
   return o;
 }
 
-__device__ bool fid_decode(const uint8_t* __restrict__ g, int w, int h, const double q[8], const uint64_t* __restrict__ codes,
-                           int ncodes, int max_hamming, int& id, int& ham, int& rot)
-{
-  double H[9];
-  if (!fid_homography(q, H)) return false;
-  uint64_t S = 0, border_hi = 0;      // payload bits are decided after the levels are known: keep the samples
-  uint8_t cell[64];
-  int bsum = 0, wsum = 0;
-  for (int r = 0; r < 8; ++r)
-    for (int c = 0; c < 8; ++c) {
-      const int s = fid_sample(g, w, h, H, (double)c + 0.5, (double)r + 0.5);
-      if (s < 0) return false;
-      cell[r * 8 + c] = (uint8_t)s;
-      if (r == 0 || r == 7 || c == 0 || c == 7) bsum += s;
-    }
-  for (int i = -1; i <= 8; ++i) {
-    const int s0 = fid_sample(g, w, h, H, (double)i + 0.5, -0.5), s1 = fid_sample(g, w, h, H, (double)i + 0.5, 8.5);
-    if (s0 < 0 || s1 < 0) return false;
-    wsum += s0 + s1;
-    if (i >= 0 && i <= 7) {
-      const int s2 = fid_sample(g, w, h, H, -0.5, (double)i + 0.5), s3 = fid_sample(g, w, h, H, 8.5, (double)i + 0.5);
-      if (s2 < 0 || s3 < 0) return false;
-      wsum += s2 + s3;
-    }
-  }
-  const int black = bsum / 28, white = wsum / 36;
-  if (white - black < 40) return false;
-  const int thr = (black + white) / 2;
-  for (int r = 0; r < 8; ++r)
-    for (int c = 0; c < 8; ++c) {
-      const int s = cell[r * 8 + c];
-      if (r == 0 || r == 7 || c == 0 || c == 7) { if (s >= thr) border_hi = 1; }
-      else if (s > thr) S |= (uint64_t)1 << (35 - ((r - 1) * 6 + (c - 1)));
-    }
-  if (border_hi) return false;
-  int best_id = -1, best_h = 99, best_rot = 0;
-  uint64_t M = S;
-  for (int rr = 0; rr < 4; ++rr) {
-    for (int k = 0; k < ncodes; ++k) {
-      const int hd = __popcll(M ^ codes[k]);
-      if (hd < best_h) { best_h = hd; best_id = k; best_rot = rr; }
-    }
-    M = fid_rot36(M);
-  }
-  if (best_id < 0 || best_h > max_hamming) return false;
-  id = best_id; ham = best_h; rot = best_rot;
-  return true;
-}
-
-// The same decode by the G lanes of a group (G | 64, lanes lg = 0..G-1 of one quad all call this with the same q; the
-// control flow is wave-uniform, so groups without a quad pass valid = false and come back with false).  fid_decode above is
-// the plain statement (one lane: ~100 dependent sample loads, a 64-entry scratch array and 4 * ncodes popcounts on a single
-// lane made it 0.2-0.4 ms of the kernel); here every lane takes 100 / G samples and ncodes / G code words, the three
-// decisions (all samples inside, contrast, border) and the best (hamming, rotation, id) are reduced over the group.
-// Same operations per sample and per code word, hence the same result.
+// Decode of one quad by the G lanes of a group (G | 64; lanes lg = 0..G-1 all call this with the same q; the control flow
+// is wave-uniform, so a group without a quad passes valid = false and comes back with false).  Definition (DESIGN.md
+// section 3, a6): homography of the 8x8-cell tag square, 64 cell samples + 36 samples of the white ring around it (all
+// must lie inside the image), black = border mean, white = ring mean, contrast >= 40, threshold at the midpoint, no white
+// border cell, payload = the 36 inner cells, best of 4 rotations x ncodes code words by (hamming, rotation, id), accepted
+// up to max_hamming.  One lane per quad made this 0.2-0.4 ms of the kernel (~100 dependent sample loads, a 64-entry
+// scratch array, 4 * ncodes popcounts on a single lane); here every lane takes 100 / G samples and ncodes / G code words
+// and the three decisions and the best key are reduced over the group: same operations per sample and per code word,
+// hence the same result.
 struct fid_hit { int16_t id; int8_t ham, rot; };      // id < 0: none
-struct fid_lane { unsigned long long best; uint32_t pk, ddt; };
+
 #define FID_QCAP 512                                   // pairs per wave: 64 lanes x 8 scan steps; 4 waves x 512 x 4 B = the s_hit array
 static_assert(sizeof(fid_hit) == 4 && FID_MAXN * sizeof(fid_hit) >= 4 * FID_QCAP * sizeof(uint32_t), "pair queue aliases s_hit");
 static_assert(FID_MAXN <= 2048, "11-bit compact corner index in the pair queue and the link key");
@@ -291,7 +246,8 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
   __shared__ fid_hit s_hit[FID_MAXN];      // by the cycle's smallest corner index
   __shared__ int16_t s_cidx[FID_MAXN];     // i of compact corner c
   __shared__ int16_t s_quad[FID_MAXN / 4]; // smallest corner index of every 4-cycle (a corner has one successor: <= n / 4 cycles)
-  __shared__ fid_lane s_lane[256];         // phase 2 (C): the lanes' corner and their best link so far
+  __shared__ unsigned long long s_best[256];   // phase 2 (C): the lanes' best link so far, distance << 11 | compact index
+  // (37.9 KB + 2 KB: four blocks per CU, so that 1024 frames are one round over 256 CUs)
   __shared__ int s_nc, s_nq;
   const int f = blockIdx.x, tid = threadIdx.x;
 #ifdef RCC_FID_TRACE
@@ -423,14 +379,12 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
     {
       const int lane = tid & 63, wbase = tid & ~63;
       uint32_t* const s_q = reinterpret_cast<uint32_t*>(s_hit) + (tid >> 6) * FID_QCAP;   // s_hit is idle until phase 3
-      fid_lane ln;
-      ln.best = ~0ull; ln.pk = pki; ln.ddt = ((uint32_t)dx & 0xFFu) | (((uint32_t)dy & 0xFFu) << 8) | ((uint32_t)t << 16);
-      s_lane[tid] = ln;
+      s_best[tid] = ~0ull;
       const bool need = act && best < 0 && npass > FK;
       int pos = need ? lo : hi;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       while (__any(pos < hi)) {
-        const unsigned long long bk = s_lane[tid].best;
+        const unsigned long long bk = s_best[tid];
         const int bestd = (bk == ~0ull) ? 0x7FFFFFFF : (int)(bk >> 11);
         int qn = 0;
         for (int st = 0; st < FID_QCAP / 64; ++st) {
@@ -448,16 +402,17 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
         for (int p = lane; p < qn; p += 64) {
           const uint32_t pr = s_q[p];
           const int L = (int)(pr & 63u), c = (int)(pr >> 6);
-          const uint32_t pkL = s_lane[wbase + L].pk, ddtL = s_lane[wbase + L].ddt, e = s_pk[c];
+          const int cL = c0 + wbase + L, iL = s_cidx[cL];                      // lane L of this wave is active: it queued the pair
+          const uint32_t pkL = s_pk[cL], e = s_pk[c];
           const int xL = (int)(pkL & 0xFFFFu), yL = (int)(pkL >> 16);
-          const int dxL = (int)(int8_t)(ddtL & 0xFFu), dyL = (int)(int8_t)((ddtL >> 8) & 0xFFu), tL = (int)(ddtL >> 16);
+          const int dxL = s_dx[iL], dyL = s_dy[iL], tL = s_thr[iL];
           const int wx = (int)(e & 0xFFFFu) - xL, wy = (int)(e >> 16) - yL;
           if (fid_edge_ok(g, w, h, xL, yL, wx, wy, -dyL, dxL, tL))
-            atomicMin(&s_lane[wbase + L].best, ((unsigned long long)(unsigned)(wx * wx + wy * wy) << 11) | (unsigned long long)c);
+            atomicMin(&s_best[wbase + L], ((unsigned long long)(unsigned)(wx * wx + wy * wy) << 11) | (unsigned long long)c);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
-      const unsigned long long bk = s_lane[tid].best;
+      const unsigned long long bk = s_best[tid];
       if (need && bk != ~0ull) best = (int)(bk & 2047ull);
     }
     if (act && best >= 0) s_nxt[i] = s_cidx[best];

@@ -8,6 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 cfg = api.default_config(); abi.set_geometry(cfg, 1920, 1080)
 family = abi.load_family(); abi.set_fiducial_target(cfg, family, tag_size=0.10, max_targets=24)
 cfg.batch_capacity = B
+if len(sys.argv) > 2: cfg.max_kept = int(sys.argv[2])
 det = api.Detector(cfg)
 frames = torch.empty((B, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
 sp = abi.default_synth_params()
