@@ -108,3 +108,67 @@ def test_hip_fiducials_match_oracle(oracle):
     assert k0 == len(dets) and worst <= 1e-4
     print("fiducials: %d tags, max pose diff vs oracle %.2e" % (k0, worst))
     det.close()
+
+
+def _clutter(img, w, h, seed, count):
+    """paste black / white / grey rectangles over a BGR frame (destroys some tags: only equality with the oracle is asked)"""
+    rng = np.random.default_rng(seed)
+    a = img.reshape(h, w, 3).copy()
+    for _ in range(count):
+        rw, rh = int(rng.integers(8, 48)), int(rng.integers(8, 48))
+        x, y = int(rng.integers(0, w - rw)), int(rng.integers(0, h - rh))
+        a[y:y + rh, x:x + rw, :] = int(rng.choice([10, 60, 200, 245]))
+    return a.reshape(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clutter", [0, 40, 120, 400])
+def test_hip_fiducials_dense_and_cluttered_scenes(oracle, clutter):
+    """48 tags at 1920x1080 (more than 256 classified corners: several passes of the linking loop) and the same scenes
+    under hundreds of pasted rectangles (corner list at its cap, most classified corners link to nothing: the pair-queue
+    fallback, pruning by the running best, quads that fail to decode): detections identical to the oracle's."""
+    import torch
+    gx, gy = 8, 6
+    cfg, fam = _cfg(api.default_config, w=1920, h=1080, B=2)
+    (hx, hy), centres, ids = synth.fiducial_grid_layout(gx, gy, cfg.tag_size)
+    sp = abi.default_synth_params()
+    sp.fid_grid_x, sp.fid_grid_y, sp.fid_gap_permille = gx, gy, 500
+    det = api.Detector(cfg)
+    n = 2
+    poses = np.concatenate([synth.sample_poses(1, cfg, seed=300 + f, z_range=(1.5, 1.9), max_tilt_deg=30, half_extent_m=(hx, hy)) for f in range(n)])
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    host = frames.cpu().numpy()
+    if clutter:
+        host = np.stack([_clutter(host[f], 1920, 1080, 7 * clutter + f, clutter) for f in range(n)])
+        frames.copy_(torch.from_numpy(host).to("cuda:0"))
+        torch.cuda.synchronize()
+    dets, fcs = det.detect(frames, n)
+    lst = det.fetch_lists(n)
+    ctx = oracle.Context(cfg)
+    k0, total, classified_max, overflowed = 0, 0, 0, 0
+    for f in range(n):
+        m, odet, ofc, st = ctx.detect(host[f], f, stages=True)
+        assert int(fcs[f].status) == int(ofc.status)
+        overflow = int(ofc.status) & (abi.RCC_FRAME_CAND_OVERFLOW | abi.RCC_FRAME_KEPT_OVERFLOW)
+        if overflow:                          # more corners than max_kept: the frame yields nothing, on both sides
+            assert m == 0
+            overflowed += 1
+        else:
+            assert lst["npre"][f] == st["npre"]
+            assert np.abs(lst["pre_xy"][f][:st["npre"]] - st["pre_xy"]).max() == 0.0
+        mine = dets[k0:k0 + m]
+        assert len(mine) == m and (mine.frame == f).all(), (len(mine), m)
+        for k in range(m):
+            a, b = mine[k], odet[k]
+            assert a.id == b.id and a.hamming == b.hamming and a.ncorners == 4 and a.pnp_status == b.pnp_status
+            assert np.abs(a.corners - np.array([[b.corners[q][0], b.corners[q][1]] for q in range(4)])).max() == 0.0
+            assert np.abs(a.rvec - np.array(b.rvec[:])).max() <= 1e-4 and np.abs(a.tvec - np.array(b.tvec[:])).max() <= 1e-4
+        k0 += m
+        total += m
+        classified_max = max(classified_max, int(st["npre"]))
+    assert k0 == len(dets)
+    if clutter == 0:
+        assert total == n * gx * gy
+    print("clutter %d: %d tags, up to %d refined corners per frame, %d frames over the cap" % (clutter, total, classified_max, overflowed))
+    det.close()
