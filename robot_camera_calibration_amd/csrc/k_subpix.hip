@@ -15,41 +15,35 @@
 #define SP_MAXW 7
 #define SP_MAXP (2 * SP_MAXW + 3)
 
-// grid (ceil(max_kept), nframes): block b handles candidate blockIdx.x of frame blockIdx.y
+// grid (max_kept, nframes): the wave handles candidate blockIdx.x of frame blockIdx.y.  (Several corners per wave, to
+// share the table setup, measured slower once the tables came from rcc_create: the longer chain per wave costs more in
+// the launch's tail than the ~15 saved loads.)
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                               rcc_subpix_params sp, int kstride, double* __restrict__ pre_xy)
+                                               rcc_subpix_params sp, const rcc_subpix_lane* __restrict__ tab, int kstride,
+                                               double* __restrict__ pre_xy)
 {
   __shared__ double S[SP_MAXP * SP_MAXP];
   const int f = blockIdx.y, q = blockIdx.x;
   if (q >= npre[f]) return;
   const int lane = threadIdx.x;
   const uint8_t* g = grey + (size_t)f * w * h;
-  const rcc_cand c0 = pre[(size_t)f * kstride + q];
   const int win = sp.win;
   const int ww = 2 * win + 1, pw = 2 * win + 3;
-  const double x0 = (double)c0.x, y0 = (double)c0.y;
-  // per-lane sample tables (the window geometry does not change between iterations): patch samples
-  // idx = lane + 64 t < pw^2 and gradient samples k = lane + 64 t < ww^2 -- no integer division in the loop
-  constexpr int PT = (SP_MAXP * SP_MAXP + 63) / 64, GT = ((2 * SP_MAXW + 1) * (2 * SP_MAXW + 1) + 63) / 64;
+  // per-lane sample tables (the window geometry does not change between corners or iterations): patch samples
+  // idx = lane + 64 t < pw^2 and gradient samples k = lane + 64 t < ww^2, tabulated at rcc_create -- no integer division here
+  constexpr int PT = RCC_SP_PT, GT = RCC_SP_GT;
+  static_assert(PT == (SP_MAXP * SP_MAXP + 63) / 64 && GT == ((2 * SP_MAXW + 1) * (2 * SP_MAXW + 1) + 63) / 64, "table shape");
+  const rcc_subpix_lane T = tab[lane];
   int poff[PT];            // (i - win - 1) * w + (j - win - 1): offset of the sample's top-left tap from (iy, ix)
   int goff[GT];            // (i + 1) * pw + (j + 1): centre of the gradient stencil in S
   double gm[GT], gpx[GT], gpy[GT];
 #pragma unroll
-  for (int t = 0; t < PT; ++t) {
-    const int idx = lane + 64 * t;
-    const int i = idx / pw, j = idx - i * pw;
-    poff[t] = (i - win - 1) * w + (j - win - 1);
-  }
+  for (int t = 0; t < PT; ++t) poff[t] = T.poff[t];
 #pragma unroll
-  for (int t = 0; t < GT; ++t) {
-    const int k = lane + 64 * t;
-    const int i = k / ww, j = k - i * ww;
-    goff[t] = (i + 1) * pw + (j + 1);
-    const bool ok = k < ww * ww;
-    gm[t] = ok ? sp.m1[i] * sp.m1[j] : 0.0;
-    gpx[t] = (double)(j - win); gpy[t] = (double)(i - win);
-  }
+  for (int t = 0; t < GT; ++t) { goff[t] = T.goff[t]; gm[t] = T.gm[t]; gpx[t] = (double)T.gpx[t]; gpy[t] = (double)T.gpy[t]; }
+  const rcc_cand c0 = pre[(size_t)f * kstride + q];
+  const double x0 = (double)c0.x, y0 = (double)c0.y;
   double cx = x0, cy = y0;
   int iter = 0;
   bool bad = false;
@@ -146,6 +140,6 @@ hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, 
   if (nframes <= 0) return hipSuccess;
   int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
   hipLaunchKernelGGL(k_subpix, dim3(max_kept, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
-                     h->d_pre, h->d_npre, h->sp, h->kept_cap, h->d_pre_xy);
+                     h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy);
   return hipGetLastError();
 }

@@ -116,7 +116,7 @@ void rcc_destroy(rcc_handle* h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = { h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
                    h->d_kept, h->d_kept_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
-                   h->d_board_obj, h->d_img_scratch, h->d_family };
+                   h->d_board_obj, h->d_img_scratch, h->d_family, h->d_sp_tab };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_det) (void)hipHostFree(h->h_det);
   if (h->h_ndet) (void)hipHostFree(h->h_ndet);
@@ -203,6 +203,31 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
         o[2] = 0.0;
       }
     if (hipMemcpy(h->d_board_obj, obj.data(), obj.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      rcc_destroy(h);
+      return RCC_ERR_DEVICE;
+    }
+  }
+  {
+    // sub-pixel sample tables, one entry per lane (k_subpix.hip)
+    const int win = cfg->subpix_win, ww = 2 * win + 1, pw = 2 * win + 3;
+    std::vector<rcc_subpix_lane> tab(64);
+    for (int lane = 0; lane < 64; ++lane) {
+      rcc_subpix_lane& e = tab[lane];
+      memset(&e, 0, sizeof(e));
+      for (int t = 0; t < RCC_SP_PT; ++t) {
+        const int idx = lane + 64 * t, i = idx / pw, j = idx - i * pw;
+        e.poff[t] = (i - win - 1) * cfg->width + (j - win - 1);
+      }
+      for (int t = 0; t < RCC_SP_GT; ++t) {
+        const int k = lane + 64 * t, i = k / ww, j = k - i * ww;
+        e.goff[t] = (i + 1) * pw + (j + 1);
+        const bool ok = k < ww * ww;
+        e.gm[t] = ok ? h->sp.m1[i] * h->sp.m1[j] : 0.0;
+        e.gpx[t] = (int8_t)(ok ? j - win : 0); e.gpy[t] = (int8_t)(ok ? i - win : 0);
+      }
+    }
+    ALLOC(h->d_sp_tab, tab.size() * sizeof(rcc_subpix_lane));
+    if (hipMemcpy(h->d_sp_tab, tab.data(), tab.size() * sizeof(rcc_subpix_lane), hipMemcpyHostToDevice) != hipSuccess) {
       rcc_destroy(h);
       return RCC_ERR_DEVICE;
     }

@@ -30,6 +30,17 @@ struct rcc_subpix_params {
   double m1[15];  // exp(-(k/win)^2), k=-win..win, computed on the host (libm)
 };
 
+// k_subpix's per-lane sample table (the window geometry is fixed per handle): built on the host at rcc_create
+#define RCC_SP_PT 5     // ceil(17 * 17 / 64): patch samples per lane at the largest window
+#define RCC_SP_GT 4     // ceil(15 * 15 / 64): gradient samples per lane
+struct rcc_subpix_lane {
+  int32_t poff[RCC_SP_PT];   // (i - win - 1) * w + (j - win - 1) of patch sample lane + 64 t
+  int32_t goff[RCC_SP_GT];   // (i + 1) * pw + (j + 1): centre of gradient sample lane + 64 t in the patch
+  int8_t gpx[RCC_SP_GT], gpy[RCC_SP_GT];   // j - win, i - win
+  int32_t pad;
+  double gm[RCC_SP_GT];      // m1[i] * m1[j], 0 beyond the window
+};
+
 struct rcc_handle {
   rcc_config cfg;
   int device;
@@ -84,6 +95,7 @@ struct rcc_handle {
   uint64_t* d_family;       // fiducial family table (device copy)
   int pnp_wave_hint;        // set per rcc_solve_pnp_batch call: max points per target > 8
   rcc_subpix_params sp;
+  rcc_subpix_lane* d_sp_tab;   // 64 entries
   char err[256];
 };
 
