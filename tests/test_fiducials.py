@@ -172,3 +172,37 @@ def test_hip_fiducials_dense_and_cluttered_scenes(oracle, clutter):
         assert total == n * gx * gy
     print("clutter %d: %d tags, up to %d refined corners per frame, %d frames over the cap" % (clutter, total, classified_max, overflowed))
     det.close()
+
+
+@pytest.mark.gpu
+def test_hip_fiducials_random_pose_sweep(oracle):
+    """48 random poses (tilt up to 55 degrees, some tags leave the frame or get too small to decode): per frame the same
+    detections as the oracle, in the same order."""
+    import torch
+    n = 48
+    cfg, fam = _cfg(api.default_config, B=n)
+    (hx, hy), centres, ids, sp = _scene(cfg)
+    det = api.Detector(cfg)
+    poses = np.concatenate([synth.sample_poses(1, cfg, seed=900 + f, z_range=(0.8, 2.6), max_tilt_deg=55, half_extent_m=(hx * 0.7, hy * 0.7))
+                            for f in range(n)])
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    dets, fcs = det.detect(frames, n)
+    host = frames.cpu().numpy()
+    ctx = oracle.Context(cfg)
+    k0, worst, partial = 0, 0.0, 0
+    for f in range(n):
+        m, odet, ofc = ctx.detect(host[f], f)
+        assert int(fcs[f].status) == int(ofc.status)
+        mine = dets[k0:k0 + m]
+        assert len(mine) == m and (mine.frame == f).all(), (f, len(mine), m)
+        for k in range(m):
+            a, b = mine[k], odet[k]
+            assert a.id == b.id and a.hamming == b.hamming and a.pnp_status == b.pnp_status
+            assert np.abs(a.corners - np.array([[b.corners[q][0], b.corners[q][1]] for q in range(4)])).max() == 0.0
+            worst = max(worst, np.abs(a.rvec - np.array(b.rvec[:])).max(), np.abs(a.tvec - np.array(b.tvec[:])).max())
+        k0 += m
+        partial += m != GX * GY
+    assert k0 == len(dets) and worst <= 1e-4
+    print("sweep: %d tags over %d frames (%d frames with fewer than %d), max pose diff %.2e" % (k0, n, partial, GX * GY, worst))
+    det.close()
