@@ -30,21 +30,25 @@
 #include "dense_band_body.h"
 
 #define BAND_ARGS const uint8_t* __restrict__ grey, int w, int h, int nbands, int nseg, int seg_tiles, int nframes, int min_contrast, \
-                  int hthresh, int margin, int cap, int allow_skip, uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count
+                  int hthresh, int margin, int cap, int allow_skip, uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count, int fchunk
 #define BAND_PASS grey, w, h, nbands, nseg, seg_tiles, nframes, min_contrast, hthresh, margin, cap, allow_skip, bin, cand, cand_count, job, lds
 // Workgroup -> job.  The hardware deals workgroup ids round-robin over the 8 XCDs, and jobs are (frame, segment, band) with
-// the band fastest: with job = workgroup id, an XCD would always get the same segment of the same residue class of frames
-// (2 segments: even XCDs the top halves, odd XCDs the bottom halves), and a batch whose targets sit in one half of the
-// image -- or in every other frame, or whose scenes repeat with a period that shares a factor with 8 -- keeps part of the
-// chip busy while the rest idles.  Measured on one box (1024 x 1080p, compact form, scratch/t_dense_flat.py): 32 scenes
-// repeated 1.10 -> 0.94 ms, top halves flat 1.11 -> 0.95, every other frame flat 1.02 -> 0.92; the bench batch (1024
-// distinct scenes) is unchanged (0.98-1.0 ms).  So XCD x takes the contiguous jobs [x ceil(njobs / 8), (x + 1) ceil(njobs / 8)):
-// whole frames, in order.  The grid is rounded up to a multiple of 8.  (Finer segments, RCC_DENSE_WANT=16, take the
-// skewed batches to 0.70-0.78 ms and cost the uniform one 3-4 %: the default stays 4.)
+// the band fastest: with job = workgroup id an XCD always gets the same segment of the same residue class of frames (2
+// segments: even XCDs the top halves, odd XCDs the bottom halves), and a batch whose activity has a period that shares a
+// factor with 8 keeps part of the chip idle (scratch/t_dense_flat.py, 1024 x 1080p, compact form, one box: every 4th frame
+// active 1.09 ms against 0.77 ms with the deal below; 32 scenes repeated 1.11 against 0.98).  So an XCD takes whole
+// frames, in chunks of `fchunk` consecutive frames (16 for a batch of 1024), and the chunks go to the XCDs along a diagonal:
+// chunk c to XCD (c + c / 8) mod 8 -- one chunk of every group of 8 per XCD, shifted by one from group to group.  A target
+// that shows up half way through the batch still loads every XCD (one contiguous eighth of the batch per XCD: 0.99 ms
+// against 0.82), no short period lands on one XCD, and consecutive frames on an XCD measure 5 % faster than single frames
+// dealt around (0.98 against 1.04 ms on the uniform batch).
+// Workgroup id -> (XCD x = id & 7, k = id >> 3); the XCD's k-th job is job k mod (fchunk jpf) of its chunk in group k / (fchunk jpf).
 #define BAND_JOB                                                                        \
-  const int njobs_ = nbands * nseg * nframes, per_xcd_ = (njobs_ + 7) >> 3;             \
-  const int job = (int)(blockIdx.x >> 3) + (int)(blockIdx.x & 7u) * per_xcd_;           \
-  if (job >= njobs_) return
+  const int jpf_ = nbands * nseg, cj_ = fchunk * jpf_, k_ = (int)(blockIdx.x >> 3);     \
+  const int grp_ = k_ / cj_, r_ = k_ - grp_ * cj_;                                      \
+  const int fr_ = (8 * grp_ + (((int)(blockIdx.x & 7u) - grp_) & 7)) * fchunk + r_ / jpf_; \
+  if (fr_ >= nframes) return;                                                           \
+  const int job = fr_ * jpf_ + r_ % jpf_
 template <int MODE, int PRIO, int NCH>
 __global__ __launch_bounds__(512) void k_dense_band(BAND_ARGS)
 {
@@ -78,13 +82,15 @@ static void launch_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8
                         int nbands, int nseg, int seg_tiles, int allow_skip, hipStream_t s)
 {
   const rcc_config& c = h->cfg;
-  const long long njobs = (((long long)nbands * nseg * nframes + 7) / 8) * 8;   // whole rounds over the 8 XCDs (BAND_JOB)
+  static const int fc_env = getenv("RCC_DENSE_FCHUNK") ? atoi(getenv("RCC_DENSE_FCHUNK")) : 0;
+  const int fchunk = fc_env > 0 ? fc_env : (nframes >= 1024 ? 16 : nframes >= 64 ? nframes / 64 : 1);   // frames per chunk (BAND_JOB)
+  const long long njobs = (long long)nbands * nseg * ((nframes + 8 * fchunk - 1) / (8 * fchunk)) * 8 * fchunk;
   if constexpr (MODE == 2)
     hipLaunchKernelGGL((k_dense_band_occ6<MODE, PRIO, NCH>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nseg, seg_tiles,
-                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count);
+                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count, fchunk);
   else
     hipLaunchKernelGGL((k_dense_band<MODE, PRIO, NCH>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nseg, seg_tiles,
-                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count);
+                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count, fchunk);
 }
 
 // h->want_thr (set by rcc_detect_batch): write the compact threshold map h->d_thr instead of the binary image

@@ -17,7 +17,7 @@ poses = np.concatenate([poses] * ((B + 31) // 32))[:B]
 for s0 in range(0, B, 64):
     det.synth_render(sp, poses[s0:s0 + 64], frames[s0:s0 + 64], first_index=s0)
 torch.cuda.synchronize()
-for name in ("flat", "bench", "half", "bottom", "oddframes", "middle", "leftflat"):
+for name in ("flat", "bench", "half", "bottom", "oddframes", "middle", "leftflat", "firsthalf", "every4th"):
     if name == "flat": grey.fill_(128)
     elif name == "bench": det.stage_ingest(frames, B, grey)
     else:
@@ -28,6 +28,10 @@ for name in ("flat", "bench", "half", "bottom", "oddframes", "middle", "leftflat
         elif name == "oddframes": g3[1::2] = 128
         elif name == "middle": g3[:, H // 4: 3 * H // 4, :] = 128
         elif name == "leftflat": g3[:, :, : W // 2] = 128
+        elif name == "firsthalf": g3[: B // 2] = 128      # the target shows up half way through the batch
+        elif name == "every4th":
+            keep = torch.arange(B, device="cuda:0") % 4 == 0
+            g3[~keep] = 128
     torch.cuda.synchronize()
     out = []
     for form, b in (("stage", binm), ("compact", None)):
