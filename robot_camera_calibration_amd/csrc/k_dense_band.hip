@@ -100,17 +100,35 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
   const rcc_config& c = h->cfg;
   const int w = c.width, ht = c.height, th = ht >> 2;
   const int nbands = (w + BAND_W - 1) / BAND_W;
-  // segments: ~4 workgroups per resident slot over the launch, at least 16 tile rows each so that the
-  // 4 warm-up / drain iterations stay a small fraction
-  int seg_tiles = th;
-  static const long long want_mul = getenv("RCC_DENSE_WANT") ? atoll(getenv("RCC_DENSE_WANT")) : 4;
-  const long long want = 256LL * 2 * want_mul;
-  while (seg_tiles > 16 && (long long)nbands * nframes * ((th + seg_tiles - 1) / seg_tiles) < want) seg_tiles = (seg_tiles + 1) / 2;
-  const int nseg = (th + seg_tiles - 1) / seg_tiles;
-  const int allow_skip = rcc_dense_allow_skip(h);
   static const int memonly = getenv("RCC_DENSE_MEMONLY") ? atoi(getenv("RCC_DENSE_MEMONLY")) : 0;
   const bool narrow = (nbands == 1) && (w <= 2048);
   const bool thr = h->want_thr && h->d_thr && !memonly;
+  // Segments per frame.  A job (one workgroup marching its segment) is a chain that takes as long alone as beside two
+  // others on the CU, so the pass is rounds of jobs over the resident slots (3 workgroups per CU for the compact form, 2
+  // for the stage form) as much as it is throughput: the count of jobs should fill whole rounds, and finer jobs pack
+  // better when the active rows are bunched (scratch/t_dense_flat.py, 1024 x 1080p compact: 2 / 3 / 4 / 5 / 6 / 9 segments
+  // 0.99 / 0.98 / 1.09 / 0.96 / 0.95 / 0.99 ms on the bench batch, 0.99 / 0.73 / 1.08 / 0.71 / 0.77 / 0.73 ms with the top half
+  // of every frame flat).  Rule: up to 6 segments of at least 32 tile rows (16 while the launch does not fill the slots);
+  // among them the largest count whose last round is within 2 % of the fullest.
+  static const int cus = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
+  const long long slots = (long long)cus * (thr ? 3 : 2), base = (long long)nbands * nframes;
+  int nseg = 1;
+  {
+    double best = 1e30;
+    for (int n = 1; n <= 16; ++n) {
+      const int st = (th + n - 1) / n;
+      const bool fills = base * n >= slots;
+      if (n > 1 && (st < 16 || (fills && (st < 32 || n > 6)))) break;
+      const long long jobs = base * ((th + st - 1) / st);
+      const double waste = (double)(((jobs + slots - 1) / slots) * slots) / (double)jobs;
+      if (waste <= best * 1.02) { if (waste < best) best = waste; nseg = n; }
+    }
+  }
+  static const int nseg_env = getenv("RCC_DENSE_NSEG") ? atoi(getenv("RCC_DENSE_NSEG")) : 0;
+  if (nseg_env > 0) nseg = nseg_env;
+  const int seg_tiles = (th + nseg - 1) / nseg;
+  nseg = (th + seg_tiles - 1) / seg_tiles;
+  const int allow_skip = rcc_dense_allow_skip(h);
   h->bin_from_thr = thr ? 1 : 0;
   if (memonly) launch_band<1, 0, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
   else if (thr && narrow) launch_band<2, 1, 8>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
