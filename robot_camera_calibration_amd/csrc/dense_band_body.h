@@ -139,6 +139,9 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
   P.reset();
   P.x0 = x0; P.w = w; P.h = h; P.t0 = t0; P.t1 = t1; P.margin = margin; P.hthresh = hthresh; P.cap = cap; P.f = f; P.lane = lane;
   P.lane_out = lane_out; P.cand = cand; P.cand_count = cand_count;
+#ifdef RCC_BAND_TRACE
+  long long tr_wait = 0, tr_act = 0; int tr_n = 0, tr_na = 0; const long long tr_0 = wall_clock64();
+#endif
   int thrB = 0, flatB = 1;
   int sf = 0;                                                  // ring slot of tile row t (scalar)
 
@@ -147,7 +150,13 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
                      const int Fa, const int Fb, int& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
     // tile row t has landed in LDS for every wave (5 = the operations each wave has issued since its DMA of
     // tile row t), every wave has finished iteration t-1, and its LDS writes are visible
+#ifdef RCC_BAND_TRACE
+    const long long tr_a = wall_clock64();
+#endif
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * BAND_DEPTH - 1) : "memory");
+#ifdef RCC_BAND_TRACE
+    const long long tr_b = wall_clock64(); tr_wait += tr_b - tr_a; ++tr_n;
+#endif
     const int sd = (sf + BAND_DEPTH >= BAND_RING) ? sf + BAND_DEPTH - BAND_RING : sf + BAND_DEPTH;
     const int sb2 = (sf >= 2) ? sf - 2 : sf + BAND_RING - 2;
     issue_dma(t + BAND_DEPTH, sd);       // the slot held tile row t-3, last read in iteration t-1
@@ -180,6 +189,9 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
           P.row(4 * tau + 2, 2, B.g2, sc, sa, sb, 0);
           P.row(4 * tau + 3, 3, B.g3, sa, sb, sc, Fb);     // produces lattice row 4*tau, in tile row tau
           if (PRIO) __builtin_amdgcn_s_setprio(0);
+#ifdef RCC_BAND_TRACE
+          tr_act += wall_clock64() - tr_b; ++tr_na;
+#endif
         } else {
           stage_out(ob, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
           P.skip();
@@ -211,5 +223,9 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
   }
   // DMA still in flight must not land in the next workgroup's LDS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef RCC_BAND_TRACE
+  if (lane == 0 && (job % 797) == 5)
+    printf("job %d wave %d: total %lld  at-barrier %lld  active-path %lld (x10ns)  iterations %d active %d\n", job, wv, wall_clock64() - tr_0, tr_wait, tr_act, tr_n, tr_na);
+#endif
 }
 
