@@ -36,12 +36,16 @@ struct BandLds { static constexpr int bytes = BAND_RING * NCH * 1024 + (MODE == 
 // threshold map (one byte per 4x4 tile: 255 = flat, else the level) -- what rcc_detect_batch needs, 1/16 of the
 // output bytes.  PRIO: raise the priority of computing waves.  NCH: 256-B chunks per staged row (8 when the frame
 // is one band of at most 2048 columns, else 9: the ring then fits three workgroups per CU).
-template <int MODE, int PRIO, int NCH>
+// SPLIT: the sweep half of the two-kernel form (k_dense_runs.hip): threshold output only -- no corner stages -- plus,
+// per (window, tile row), the 64-bit ballot of the lanes' flat flags (`flat`, layout rcc_flat_index), from which the
+// corner kernel takes the rows it has to visit and the per-lane response masks.
+template <int MODE, int PRIO, int NCH, bool SPLIT = false>
 __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey, int w, int h,
                                                 int nbands, int nseg, int seg_tiles, int nframes,
                                                 int min_contrast, int hthresh, int margin, int cap, int allow_skip,
                                                 uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand,
-                                                int32_t* __restrict__ cand_count, const int job, uint8_t* lds /* BAND_LDS<MODE, NCH> bytes, 1 KiB aligned */)
+                                                int32_t* __restrict__ cand_count, const int job, uint8_t* lds /* BAND_LDS<MODE, NCH> bytes, 1 KiB aligned */,
+                                                unsigned long long* __restrict__ flat = nullptr, int flat_tp = 0)
 {
   constexpr int BAND_SLOT = NCH * 1024;
   constexpr bool THR = (MODE == 2);
@@ -67,6 +71,8 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
   const int out_bytes = THR ? th * RCC_THR_PITCH : w * h;
   uint8_t* bo = THR ? bin + ((size_t)f * nbands + band) * (size_t)th * RCC_THR_PITCH : bin + (size_t)f * w * h;
   if (margin < 6) margin = 6;
+  // SPLIT: this window's row of flat masks; entry x + 1 describes tile row x (-1 .. th: the image's border rows included)
+  unsigned long long* const fm = SPLIT ? flat + rcc_flat_index(f, band, wv, nbands, flat_tp) : nullptr;
 
   // ---- addressing constants
   const uint64_t ga = (uint64_t)(uintptr_t)gf;
@@ -176,7 +182,23 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
       // ---- BACK
       const int tau = t - 2;
       if (THR) stage_thr(ob, flatB ? 255 : thrB);            // tile row tau's level (thrB <= 254 when not flat)
-      if (tau >= t0 - 2) {
+      if (SPLIT) {
+        // true flatness of tile row t-1, for the rows this segment owns (every row is written by exactly one segment)
+        const int xr = t - 1;
+        if ((xr >= t0 && xr < t1) || (xr == -1 && t0 == 0) || (xr == th && t1 == th)) {
+          const unsigned long long m = __ballot(flatN != 0);
+          if (lane == 0) fm[xr + 1] = m;
+        }
+        if (!THR && tau >= t0 - 2) {
+          if (__any(lane_out && !flatB)) {
+            const Tile4 B = read_tile(sb2);
+            const Thr4 thr(thrB, flatB);
+            stage_out(ob, thr(B.g0), thr(B.g1), thr(B.g2), thr(B.g3));
+          } else {
+            stage_out(ob, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
+          }
+        }
+      } else if (tau >= t0 - 2) {
         if (__any(lane_core && !(Fa && Fb && Fn))) {   // halo lanes do not vote: nothing they hold reaches an output
           if (PRIO) __builtin_amdgcn_s_setprio(2);          // the wave on the critical path of this iteration
           const Tile4 B = read_tile(sb2);

@@ -30,8 +30,9 @@
 #include "dense_band_body.h"
 
 #define BAND_ARGS const uint8_t* __restrict__ grey, int w, int h, int nbands, int nseg, int seg_tiles, int nframes, int min_contrast, \
-                  int hthresh, int margin, int cap, int allow_skip, uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count, int fchunk
-#define BAND_PASS grey, w, h, nbands, nseg, seg_tiles, nframes, min_contrast, hthresh, margin, cap, allow_skip, bin, cand, cand_count, job, lds
+                  int hthresh, int margin, int cap, int allow_skip, uint8_t* __restrict__ bin, rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count, int fchunk, \
+                  unsigned long long* __restrict__ flat, int flat_tp
+#define BAND_PASS grey, w, h, nbands, nseg, seg_tiles, nframes, min_contrast, hthresh, margin, cap, allow_skip, bin, cand, cand_count, job, lds, flat, flat_tp
 // Workgroup -> job.  The hardware deals workgroup ids round-robin over the 8 XCDs, and jobs are (frame, segment, band) with
 // the band fastest: with job = workgroup id an XCD always gets the same segment of the same residue class of frames (2
 // segments: even XCDs the top halves, odd XCDs the bottom halves), and a batch whose activity has a period that shares a
@@ -49,12 +50,12 @@
   const int fr_ = (8 * grp_ + (((int)(blockIdx.x & 7u) - grp_) & 7)) * fchunk + r_ / jpf_; \
   if (fr_ >= nframes) return;                                                           \
   const int job = fr_ * jpf_ + r_ % jpf_
-template <int MODE, int PRIO, int NCH>
+template <int MODE, int PRIO, int NCH, bool SPLIT = false>
 __global__ __launch_bounds__(512) void k_dense_band(BAND_ARGS)
 {
   __shared__ __attribute__((aligned(1024))) uint8_t lds[BandLds<MODE, NCH>::bytes];
   BAND_JOB;
-  dense_band_body<MODE, PRIO, NCH>(BAND_PASS);
+  dense_band_body<MODE, PRIO, NCH, SPLIT>(BAND_PASS);
 }
 // the compact-map form needs 42-47 KB of LDS: three workgroups per CU fit if the kernel stays within 80 VGPRs
 // (6 waves per SIMD); measured 1.26 -> 1.18 ms per 1024 x 1080p and 1.44 -> 1.32 ms per 256 x 4K with the cap (6-8
@@ -77,7 +78,7 @@ bool rcc_dense_band_supported(const rcc_handle* h, const uint8_t* d_grey, const 
 
 int rcc_dense_allow_skip(const rcc_handle* h);
 
-template <int MODE, int PRIO, int NCH>
+template <int MODE, int PRIO, int NCH, bool SPLIT = false>
 static void launch_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_out, rcc_cand* d_cand, int32_t* d_cand_count,
                         int nbands, int nseg, int seg_tiles, int allow_skip, hipStream_t s)
 {
@@ -85,17 +86,26 @@ static void launch_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8
   static const int fc_env = getenv("RCC_DENSE_FCHUNK") ? atoi(getenv("RCC_DENSE_FCHUNK")) : 0;
   const int fchunk = fc_env > 0 ? fc_env : (nframes >= 1024 ? 16 : nframes >= 64 ? nframes / 64 : 1);   // frames per chunk (BAND_JOB)
   const long long njobs = (long long)nbands * nseg * ((nframes + 8 * fchunk - 1) / (8 * fchunk)) * 8 * fchunk;
-  if constexpr (MODE == 2)
+  const int tp = rcc_flat_tp(c.height);
+  if constexpr (SPLIT)
+    hipLaunchKernelGGL((k_dense_band<MODE, PRIO, NCH, true>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nseg, seg_tiles,
+                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count, fchunk,
+                       h->d_flat, tp);
+  else if constexpr (MODE == 2)
     hipLaunchKernelGGL((k_dense_band_occ6<MODE, PRIO, NCH>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nseg, seg_tiles,
-                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count, fchunk);
+                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count, fchunk,
+                       (unsigned long long*)nullptr, 0);
   else
     hipLaunchKernelGGL((k_dense_band<MODE, PRIO, NCH>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nseg, seg_tiles,
-                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count, fchunk);
+                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count, fchunk,
+                       (unsigned long long*)nullptr, 0);
 }
 
 // h->want_thr (set by rcc_detect_batch): write the compact threshold map h->d_thr instead of the binary image
+// split != 0: the two-kernel form -- this launch only thresholds and leaves the flat masks (h->d_flat), the corner
+// stages follow in k_dense_runs (k_dense_runs.hip)
 hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
-                                 rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s)
+                                 rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s, int split)
 {
   const rcc_config& c = h->cfg;
   const int w = c.width, ht = c.height, th = ht >> 2;
@@ -130,6 +140,24 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
   nseg = (th + seg_tiles - 1) / seg_tiles;
   const int allow_skip = rcc_dense_allow_skip(h);
   h->bin_from_thr = thr ? 1 : 0;
+  if (split) {
+    const int tp = rcc_flat_tp(ht);
+    const size_t need = rcc_flat_index(h->cfg.batch_capacity > nframes ? h->cfg.batch_capacity : nframes, 0, 0, nbands, tp) * sizeof(unsigned long long);
+    if (need > h->flat_bytes) {
+      if (h->d_flat) (void)hipFree(h->d_flat);
+      h->d_flat = nullptr; h->flat_bytes = 0;
+      hipError_t e = hipMalloc((void**)&h->d_flat, need);
+      if (e != hipSuccess) return e;
+      h->flat_bytes = need;
+    }
+    if (thr && narrow) launch_band<2, 0, 8, true>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+    else if (thr) launch_band<2, 0, 9, true>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+    else if (narrow) launch_band<0, 0, 8, true>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+    else launch_band<0, 0, 9, true>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return rcc_launch_dense_runs(h, d_grey, nframes, h->d_flat, tp, d_cand, d_cand_count, s);
+  }
   if (memonly) launch_band<1, 0, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
   else if (thr && narrow) launch_band<2, 1, 8>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
   else if (thr) launch_band<2, 1, 9>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);

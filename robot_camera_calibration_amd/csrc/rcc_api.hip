@@ -114,7 +114,7 @@ void rcc_destroy(rcc_handle* h)
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = { h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
+  void* ptrs[] = { h->d_flat, h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
                    h->d_kept, h->d_kept_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
                    h->d_board_obj, h->d_img_scratch, h->d_family, h->d_sp_tab };
   for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -11,6 +11,15 @@
 #define RCC_THR_PITCH 512     // bytes per tile row of one band in the compact threshold map (480 used at 1920 columns)
 #define RCC_BAND_W 1920        // output columns per band of the band kernel
 
+// Flat masks of the two-kernel threshold + corner pass (k_dense_band.hip sweep -> k_dense_runs.hip): one 64-bit word per
+// (frame, band, window of the band, tile row): bit l = lane l's 4x4 tile has a dilated contrast below min_contrast.
+// A window's words are contiguous: entry x + 1 describes tile row x, x = -1 .. th (tp >= th + 2 entries).
+__host__ __device__ inline size_t rcc_flat_index(int f, int band, int window, int nbands, int tp)
+{
+  return (((size_t)f * nbands + band) * 8 + window) * (size_t)tp;
+}
+inline int rcc_flat_tp(int height) { return (((height >> 2) + 2) + 7) & ~7; }
+
 struct rcc_cand {  // dense-pass list entry, 8 bytes
   int16_t x, y;
   int32_t score;
@@ -51,6 +60,8 @@ struct rcc_handle {
   uint8_t* d_bin;
   uint8_t* d_thr;           // compact threshold map of rcc_detect_batch: per frame [band][tile row][RCC_THR_PITCH] bytes,
                             // one per 4x4 tile: 255 = flat tile (binary value 127), else the level (pixel > level ? 255 : 0)
+  unsigned long long* d_flat;   // flat masks of the split threshold + corner pass (rcc_flat_index), allocated on first use
+  size_t flat_bytes;
   int fuse_grid_pnp;        // 1 (default): board validation / indexing and pose in one kernel (checkerboard, wave-per-board solver)
   int keep_bin;             // rcc_set_keep_binary: rcc_detect_batch writes the full binary image (default 0: the compact map)
   int want_thr;             // set by rcc_detect_batch: the dense pass may write d_thr instead of the full binary image
@@ -103,6 +114,8 @@ struct rcc_handle {
 hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes, uint8_t* d_grey, hipStream_t s);
 hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
                             rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
+hipError_t rcc_launch_dense_runs(rcc_handle* h, const uint8_t* d_grey, int nframes, const unsigned long long* d_flat, int flat_tp,
+                                 rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
 hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t* d_cand_count,
                            int nframes, hipStream_t s);
 hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);

@@ -286,8 +286,8 @@ def test_edge_cases(torch_cuda, oracle):
         api.Detector(bad)
 
 
-# dense pass: (variant, flat-row skip) -- 0 generic LDS tiles, 1 band kernel, 2 strip march
-DENSE_VARIANTS = ((0, 1), (1, 1), (1, 0), (2, 1), (2, 0))
+# dense pass: (variant, flat-row skip) -- 0 generic LDS tiles, 1 band kernel, 2 strip march, 3 band sweep + corner kernel on the active rows
+DENSE_VARIANTS = ((0, 1), (1, 1), (1, 0), (2, 1), (2, 0), (3, 1), (3, 0))
 
 
 @pytest.mark.parametrize("pixfmt,w,h,n", [(abi.RCC_PIX_BGR8, 640, 480, 5), (abi.RCC_PIX_MONO8, 640, 480, 5),
@@ -344,16 +344,24 @@ def test_compact_threshold_map_identical(torch_cuda, w, h, n):
     det = api.Detector(cfg)
     frames, _ = _render(torch, det, cfg, n, seed=77)
     torch.cuda.synchronize()
-    det.set_keep_binary(0)
-    d0, f0 = det.detect(frames, n)
-    img0 = det.fetch_images(n)
-    det.set_keep_binary(1)
-    d1, f1 = det.detect(frames, n)
-    img1 = det.fetch_images(n)
-    assert len(d0) == len(d1) == n
-    assert d0.tobytes() == d1.tobytes() and f0.tobytes() == f1.tobytes()
-    assert (img0["bin"] == img1["bin"]).all() and (img0["grey"] == img1["grey"]).all()
-    assert set(np.unique(img0["bin"]).tolist()) <= {0, 127, 255}
+    ref = None
+    for variant in (1, 3):                 # fused band kernel; band sweep + corner kernel on the active rows
+        det.set_dense_variant(variant)
+        det.set_keep_binary(0)
+        d0, f0 = det.detect(frames, n)
+        img0 = det.fetch_images(n)
+        det.set_keep_binary(1)
+        d1, f1 = det.detect(frames, n)
+        img1 = det.fetch_images(n)
+        assert len(d0) == len(d1) == n
+        assert d0.tobytes() == d1.tobytes() and f0.tobytes() == f1.tobytes()
+        assert (img0["bin"] == img1["bin"]).all() and (img0["grey"] == img1["grey"]).all()
+        assert set(np.unique(img0["bin"]).tolist()) <= {0, 127, 255}
+        assert (img0["cand_count"] == img1["cand_count"]).all()
+        if ref is None:
+            ref = (d0.tobytes(), f0.tobytes(), img0["bin"].copy(), img0["cand_count"].copy())
+        else:
+            assert d0.tobytes() == ref[0] and f0.tobytes() == ref[1] and (img0["bin"] == ref[2]).all() and (img0["cand_count"] == ref[3]).all()
     det.close()
 
 
