@@ -210,6 +210,21 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
                             rcc_frame_corners* corners, void* stream);
 int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet);
 
+/* ---- records for the exchange between processes (multi-GPU) -------------------------------------
+ * Between processes the reference hands detections on over the "tag_detections" topic (corner_detections.cpp:78); with
+ * one process per GPU the per-batch stand-in is ONE all-gather of fixed-size records.  rcc_set_record_tables makes
+ * every following rcc_detect_batch / rcc_detect_batch_submit also write, on the device and on the batch's stream, a
+ * table of RCC_REC_DOUBLES doubles per slot into the caller's DEVICE buffer (rcc_record_slots(nframes) slots; slot =
+ * frame * targets_per_frame + q, all zeros where there is no target):
+ *   [0] valid (1.0)  [1] frame_offset + frame  [2] id  [3] ncorners  [4..6] rvec  [7..9] tvec  [10] rms
+ *   [11..18] the four corners bl, br, tr, tl as x,y -- all four, as the consumer reads them (corner_detections.cpp:51-56)
+ * d_table0 serves rcc_detect_batch and the submissions in result slot 0, d_table1 those in slot 1 (NULL: d_table0 for
+ * both -- then a table must be consumed before the next submission).  A submission's table is complete when its
+ * rcc_detect_batch_collect returns.  NULL, NULL switches the tables off.  include/rcc_dist.h gathers such tables over RCCL. */
+#define RCC_REC_DOUBLES 19
+int rcc_set_record_tables(rcc_handle* h, double* d_table0, double* d_table1, int32_t frame_offset);
+int rcc_record_slots(const rcc_handle* h, int32_t nframes);
+
 /* a1+a2: ingest = BGR->grey (+ undistort when cfg.undistort).  src/dst device pointers;
  * dst is nframes tightly packed width*height u8 images. */
 int rcc_stage_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey, void* stream);
@@ -256,6 +271,9 @@ int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, cons
  * [3] pnp, [4] d2h (with rcc_set_fuse_grid_pnp(1), the default for checkerboards, the grid stage runs inside the
  * pose kernel and is counted in [3]).  Returns the number of slots written. */
 int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n);
+/* name(s) of the kernel(s) the handle's last threshold + corner launch used, spelled as rocprofv3's kernel trace prints
+ * them (bench.py quotes it beside the roofline figure, so that the figure can be matched with profiles/) */
+const char* rcc_last_dense_kernel(const rcc_handle* h);
 /* Launch the dense pass `reps` times back to back and return the mean kernel time in ms measured
  * with HIP events on the launch stream (bench.py's roofline leg).  d_bin == NULL times the form
  * rcc_detect_batch runs: binary image left as the compact threshold map in the handle (nframes <= batch_capacity). */

@@ -24,33 +24,47 @@ def build(force=False):
     return so
 
 
+def _bind(so):
+    L = C.CDLL(so)
+    P = C.c_void_p
+    L.orc_atan_pos.restype = C.c_double
+    L.orc_atan_pos.argtypes = [C.c_double]
+    L.orc_ctx_create.restype = P
+    L.orc_ctx_create.argtypes = [C.POINTER(abi.rcc_config)]
+    L.orc_ctx_destroy.argtypes = [P]
+    L.orc_ctx_detect.restype = C.c_int
+    L.orc_ctx_detect.argtypes = [P, P, C.c_int, P, P, P, P, P, P, P, P, P, P, P]
+    L.orc_validate_refined.restype = C.c_int
+    L.orc_ctx_detect_many.restype = C.c_int
+    L.orc_ctx_detect_many.argtypes = [P, P, C.c_int64, C.c_int, P]
+    L.orc_default_config.argtypes = [C.POINTER(abi.rcc_config)]
+    L.orc_solve_pnp.restype = C.c_int
+    L.orc_grid_index.restype = C.c_int
+    L.orc_harris_candidates.restype = C.c_int
+    L.orc_filter_candidates.restype = C.c_int
+    L.orc_find_homography.restype = C.c_int
+    L.orc_xjunction_ring.restype = C.c_int
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
         so = os.environ.get("ORC_LIBRARY") or os.path.join(_HERE, "liborc.so")   # ORC_LIBRARY: e.g. a sanitizer build
         if not os.path.exists(so):
             build()
-        L = C.CDLL(so)
-        P = C.c_void_p
-        L.orc_atan_pos.restype = C.c_double
-        L.orc_atan_pos.argtypes = [C.c_double]
-        L.orc_ctx_create.restype = P
-        L.orc_ctx_create.argtypes = [C.POINTER(abi.rcc_config)]
-        L.orc_ctx_destroy.argtypes = [P]
-        L.orc_ctx_detect.restype = C.c_int
-        L.orc_ctx_detect.argtypes = [P, P, C.c_int, P, P, P, P, P, P, P, P, P, P, P]
-        L.orc_validate_refined.restype = C.c_int
-        L.orc_ctx_detect_many.restype = C.c_int
-        L.orc_ctx_detect_many.argtypes = [P, P, C.c_int64, C.c_int, P]
-        L.orc_default_config.argtypes = [C.POINTER(abi.rcc_config)]
-        L.orc_solve_pnp.restype = C.c_int
-        L.orc_grid_index.restype = C.c_int
-        L.orc_harris_candidates.restype = C.c_int
-        L.orc_filter_candidates.restype = C.c_int
-        L.orc_find_homography.restype = C.c_int
-        L.orc_xjunction_ring.restype = C.c_int
-        _LIB = L
+        _LIB = _bind(so)
     return _LIB
+
+
+def native_library():
+    """The same sources built -O3 -march=native for the host it runs on (oracle/_native/liborc.so, `make native`):
+    bench.py's cpu_baseline leg times this build; every check uses lib().  Built on first use (gcc is on the GPU box)."""
+    so = os.path.join(_HERE, "_native", "liborc.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "native"], stdout=subprocess.DEVNULL)
+    return _bind(so)
 
 
 def _p(a):
@@ -239,15 +253,16 @@ def synth_render(cfg, sp, pose, frame_index):
 class Context:
     """One oracle context = one configuration (holds the undistortion map and scratch)."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, library=None):
         self.cfg = cfg
-        self._c = lib().orc_ctx_create(C.byref(cfg))
+        self._L = library if library is not None else lib()
+        self._c = self._L.orc_ctx_create(C.byref(cfg))
         if not self._c:
             raise MemoryError("orc_ctx_create failed")
 
     def close(self):
         if self._c:
-            lib().orc_ctx_destroy(self._c)
+            self._L.orc_ctx_destroy(self._c)
             self._c = None
 
     def __del__(self):
@@ -270,16 +285,16 @@ class Context:
             nc = C.c_int32(0)
             nk = C.c_int32(0)
             npre = C.c_int32(0)
-            n = lib().orc_ctx_detect(self._c, _p(frame), frame_index, dref, C.byref(fc), _p(grey), _p(binm), _p(cand), C.byref(nc),
+            n = self._L.orc_ctx_detect(self._c, _p(frame), frame_index, dref, C.byref(fc), _p(grey), _p(binm), _p(cand), C.byref(nc),
                                      _p(pre), C.byref(npre), _p(pre_xy), _p(kept), C.byref(nk))
             return n, det, fc, dict(grey=grey, bin=binm, cand=cand[:min(nc.value, cfg.max_candidates)], ncand=nc.value,
                                     pre=pre[:min(npre.value, abi.RCC_MAX_KEPT_FIDUCIAL)], npre=npre.value, pre_xy=pre_xy[:min(npre.value, abi.RCC_MAX_KEPT_FIDUCIAL)],
                                     kept=kept[:min(nk.value, 256)], nkept=nk.value)
-        n = lib().orc_ctx_detect(self._c, _p(frame), frame_index, dref, C.byref(fc), None, None, None, None, None, None, None, None, None)
+        n = self._L.orc_ctx_detect(self._c, _p(frame), frame_index, dref, C.byref(fc), None, None, None, None, None, None, None, None, None)
         return n, det, fc
 
     def detect_many(self, frames, nframes):
         frames = np.ascontiguousarray(frames, np.uint8)
         dets = (abi.rcc_detection * nframes)()
-        n = lib().orc_ctx_detect_many(self._c, _p(frames), C.c_int64(self.cfg.frame_bytes), nframes, dets)
+        n = self._L.orc_ctx_detect_many(self._c, _p(frames), C.c_int64(self.cfg.frame_bytes), nframes, dets)
         return n, dets

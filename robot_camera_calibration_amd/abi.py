@@ -18,6 +18,7 @@ RCC_MEM_HOST, RCC_MEM_DEVICE = 0, 1
 RCC_FRAME_OK, RCC_FRAME_CAND_OVERFLOW, RCC_FRAME_NOT_FOUND, RCC_FRAME_KEPT_OVERFLOW = 0, 1, 2, 4
 RCC_PNP_OK, RCC_PNP_TOO_FEW, RCC_PNP_NONPLANAR, RCC_PNP_DEGENERATE = 0, 1, 2, 3
 RCC_MAX_BOARD_CORNERS = 256
+RCC_REC_DOUBLES = 19   # doubles per slot of the record tables ranks exchange (include/rcc.h)
 
 
 class rcc_config(C.Structure):

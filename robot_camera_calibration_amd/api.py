@@ -90,6 +90,12 @@ def load_library():
     L.rcc_debug_fetch_images.argtypes = [P, I, P, P, P, P]
     L.rcc_debug_calib_copy.argtypes = [P, P, P, C.c_int64]
     L.rcc_debug_calib_copy.restype = C.c_int
+    L.rcc_last_dense_kernel.argtypes = [P]
+    L.rcc_last_dense_kernel.restype = C.c_char_p
+    L.rcc_set_record_tables.argtypes = [P, P, P, I]
+    L.rcc_set_record_tables.restype = C.c_int
+    L.rcc_record_slots.argtypes = [P, I]
+    L.rcc_record_slots.restype = C.c_int
     for name in ("rcc_create", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
                  "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_stage_targets",
                  "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_last_timings", "rcc_time_dense",
@@ -108,8 +114,15 @@ EXPORTED_SYMBOLS = (
     "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_set_dense_variant",
     "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_set_dense_skip", "rcc_set_keep_binary", "rcc_set_fuse_grid_pnp", "rcc_detect_batch_submit", "rcc_detect_batch_collect", "rcc_debug_overlap", "rcc_set_pipeline", "rcc_time_copy", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
     "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch", "rcc_debug_calib_copy",
-    "rcc_debug_pnp_probe",
+    "rcc_debug_pnp_probe", "rcc_set_record_tables", "rcc_record_slots", "rcc_last_dense_kernel",
 )
+# include/rcc_dist.h (librcc_dist.so: the RCCL all-gather of the record tables for non-Python hosts)
+DIST_EXPORTED_SYMBOLS = ("rcc_dist_unique_id", "rcc_dist_create", "rcc_dist_destroy", "rcc_dist_rank", "rcc_dist_world",
+                         "rcc_dist_allgather_records", "rcc_dist_last_error")
+
+
+def dist_library_path():
+    return os.path.join(_HERE, "librcc_dist.so")
 
 
 def status_string(status):
@@ -124,6 +137,13 @@ def default_config():
     cfg = abi.rcc_config()
     load_library().rcc_default_config(C.byref(cfg))
     return cfg
+
+
+def clone_config(cfg):
+    """a byte copy of an rcc_config (pointers inside -- the family table -- are shared)"""
+    c = abi.rcc_config()
+    C.memmove(C.byref(c), C.byref(cfg), C.sizeof(abi.rcc_config))
+    return c
 
 
 def _ptr(x):
@@ -217,11 +237,13 @@ class Detector:
         self._chk(self._L.rcc_detect_batch_submit(self._h, _ptr(frames), nframes, mem, _ptr(fc), _ptr(stream)), "rcc_detect_batch_submit")
         if not hasattr(self, "_pending"):
             self._pending = []
-        self._pending.append((frames, nframes, fc))
+            self._nsub = 0
+        self._pending.append((frames, nframes, fc, self._nsub & 1))
+        self._nsub += 1
 
     def collect(self):
         """results of the oldest outstanding submit(): (detections, frame_corners or None), as detect() returns them"""
-        frames, nframes, fc = self._pending.pop(0)
+        frames, nframes, fc, self.last_slot = self._pending.pop(0)      # last_slot: which record table holds this batch
         det = np.zeros(max(nframes * self.cfg.max_targets, 1), DET_DT)
         ndet = C.c_int32(0)
         self._chk(self._L.rcc_detect_batch_collect(self._h, _ptr(det), C.byref(ndet)), "rcc_detect_batch_collect")
@@ -279,6 +301,17 @@ class Detector:
         self._chk(st, "rcc_stage_targets")
         return det[:ndet.value].view(np.recarray), (fc[:nframes].view(np.recarray) if fc is not None else None)
 
+    def record_slots(self, nframes):
+        """slots of the record table of an nframes batch (rcc_set_record_tables)"""
+        return int(self._L.rcc_record_slots(self._h, int(nframes)))
+
+    def set_record_tables(self, t0, t1=None, frame_offset=0):
+        """Device tables (record_slots(n) x abi.RCC_REC_DOUBLES float64 each) that every following detect() / submit()
+        also fills on the device: t0 for detect() and submissions in result slot 0, t1 for those in slot 1.  The
+        tensors must stay alive while they are registered; (None, None) switches the tables off."""
+        self._rec_tables = (t0, t1)
+        self._chk(self._L.rcc_set_record_tables(self._h, _ptr(t0), _ptr(t1), int(frame_offset)), "rcc_set_record_tables")
+
     def set_dense_variant(self, v):
         return self._L.rcc_set_dense_variant(self._h, int(v))
 
@@ -312,6 +345,9 @@ class Detector:
         ms = (C.c_float * 5)()
         self._L.rcc_last_timings(self._h, ms, 5)
         return dict(zip(("ingest", "dense", "list_subpix_grid", "pnp", "d2h"), [float(v) for v in ms]))
+
+    def last_dense_kernel(self):
+        return self._L.rcc_last_dense_kernel(self._h).decode()
 
     def time_dense(self, d_grey, nframes, d_bin, d_cand, d_count, reps):
         ms = C.c_float(0)

@@ -217,7 +217,8 @@ hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, u
   if (variant == 2 && !march_ok) variant = 0;
   h->bin_from_thr = 0;      // only the band kernel can leave the binary image as the compact threshold map
   if (variant == 1 || variant == 3) return rcc_launch_dense_band(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s, variant == 3);
-  if (variant == 2) return rcc_launch_dense_march(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s);
+  if (variant == 2) { h->dense_kernel = "k_dense_march<0>"; return rcc_launch_dense_march(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s); }
+  h->dense_kernel = "k_dense_lds";
   const int w = c.width, ht = c.height;
   int tw = w >> 2, th = ht >> 2;
   if (tw < 1) tw = 1;

@@ -150,18 +150,18 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
       if (e != hipSuccess) return e;
       h->flat_bytes = need;
     }
-    if (thr && narrow) launch_band<2, 0, 8, true>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
-    else if (thr) launch_band<2, 0, 9, true>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
-    else if (narrow) launch_band<0, 0, 8, true>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
-    else launch_band<0, 0, 9, true>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+    if (thr && narrow) { h->dense_kernel = "k_dense_band<2, 0, 8, true> + k_dense_runs"; launch_band<2, 0, 8, true>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
+    else if (thr) { h->dense_kernel = "k_dense_band<2, 0, 9, true> + k_dense_runs"; launch_band<2, 0, 9, true>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
+    else if (narrow) { h->dense_kernel = "k_dense_band<0, 0, 8, true> + k_dense_runs"; launch_band<0, 0, 8, true>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
+    else { h->dense_kernel = "k_dense_band<0, 0, 9, true> + k_dense_runs"; launch_band<0, 0, 9, true>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return rcc_launch_dense_runs(h, d_grey, nframes, h->d_flat, tp, d_cand, d_cand_count, s);
   }
-  if (memonly) launch_band<1, 0, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
-  else if (thr && narrow) launch_band<2, 1, 8>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
-  else if (thr) launch_band<2, 1, 9>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
-  else if (narrow) launch_band<0, 1, 8>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
-  else launch_band<0, 1, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s);
+  if (memonly) { h->dense_kernel = "k_dense_band<1, 0, 9, false>"; launch_band<1, 0, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
+  else if (thr && narrow) { h->dense_kernel = "k_dense_band_occ6<2, 1, 8>"; launch_band<2, 1, 8>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
+  else if (thr) { h->dense_kernel = "k_dense_band_occ6<2, 1, 9>"; launch_band<2, 1, 9>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
+  else if (narrow) { h->dense_kernel = "k_dense_band<0, 1, 8, false>"; launch_band<0, 1, 8>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
+  else { h->dense_kernel = "k_dense_band<0, 1, 9, false>"; launch_band<0, 1, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
   return hipGetLastError();
 }

@@ -273,6 +273,8 @@ int rcc_set_ingest_variant(rcc_handle* h, int variant)
   return p;
 }
 
+const char* rcc_last_dense_kernel(const rcc_handle* h) { return (h && h->dense_kernel) ? h->dense_kernel : ""; }
+
 int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n)
 {
   if (!h || !ms) return RCC_ERR_ARG;
@@ -479,6 +481,7 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
       HIPCHK(h, hipStreamWaitEvent(s, h->pev[1 + k], 0));
     }
     for (float& m : h->last_ms) m = -1.0f;
+    if (h->rec_table[0]) HIPCHK(h, rcc_launch_pack_records(h, nframes, h->rec_offset, h->rec_table[0], s));
     return collect_targets(h, nframes, det, ndet, corners, s, false);
   }
   HIPCHK(h, hipEventRecord(h->ev[0], s));
@@ -489,7 +492,10 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
   h->want_thr = h->keep_bin ? 0 : 1;
   HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
   h->want_thr = 0;
-  int r = run_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, det, ndet, corners, s);
+  int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, true);
+  if (r != RCC_OK) return r;
+  if (h->rec_table[0]) HIPCHK(h, rcc_launch_pack_records(h, nframes, h->rec_offset, h->rec_table[0], s));
+  r = collect_targets(h, nframes, det, ndet, corners, s, true);
   if (r != RCC_OK) return r;
   (void)hipEventElapsedTime(&h->last_ms[0], h->ev[0], h->ev[1]);
   (void)hipEventElapsedTime(&h->last_ms[1], h->ev[1], h->ev[2]);
@@ -530,6 +536,7 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   h->want_thr = 0;
   int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, false);
   if (r != RCC_OK) return r;
+  if (h->rec_table[slot]) HIPCHK(h, rcc_launch_pack_records(h, nframes, h->rec_offset, h->rec_table[slot], s));
   rcc_detection* hd = slot ? h->h_det2 : h->h_det;
   int32_t* hn = slot ? h->h_ndet2 : h->h_ndet;
   HIPCHK(h, hipMemcpyAsync(hd, h->d_det, sizeof(rcc_detection) * (size_t)nframes * (fid ? slots : 1), hipMemcpyDeviceToHost, s));
@@ -567,6 +574,21 @@ int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet)
   h->sub_nframes[slot] = 0;
   ++h->sub_tail;
   return RCC_OK;
+}
+
+// record tables for the exchange between ranks (k_records.hip)
+int rcc_set_record_tables(rcc_handle* h, double* d_table0, double* d_table1, int32_t frame_offset)
+{
+  if (!h || (d_table1 && !d_table0)) return RCC_ERR_ARG;
+  if (h->sub_head != h->sub_tail) return RCC_ERR_STATE;
+  h->rec_table[0] = d_table0; h->rec_table[1] = d_table1 ? d_table1 : d_table0;
+  h->rec_offset = frame_offset;
+  return RCC_OK;
+}
+int rcc_record_slots(const rcc_handle* h, int32_t nframes)
+{
+  if (!h || nframes < 0) return RCC_ERR_ARG;
+  return nframes * (h->cfg.target_kind == RCC_TARGET_FIDUCIAL ? h->cfg.max_targets : 1);
 }
 
 int rcc_set_fuse_grid_pnp(rcc_handle* h, int on)

@@ -62,6 +62,9 @@ struct rcc_handle {
                             // one per 4x4 tile: 255 = flat tile (binary value 127), else the level (pixel > level ? 255 : 0)
   unsigned long long* d_flat;   // flat masks of the split threshold + corner pass (rcc_flat_index), allocated on first use
   size_t flat_bytes;
+  double* rec_table[2];     // rcc_set_record_tables: the caller's device tables, one per result slot (NULL: none)
+  int rec_offset;           // global index of the batch's first frame in those tables
+  const char* dense_kernel; // name(s) of the kernel(s) the last threshold + corner launch used, as rocprofv3 prints them
   int fuse_grid_pnp;        // 1 (default): board validation / indexing and pose in one kernel (checkerboard, wave-per-board solver)
   int keep_bin;             // rcc_set_keep_binary: rcc_detect_batch writes the full binary image (default 0: the compact map)
   int want_thr;             // set by rcc_detect_batch: the dense pass may write d_thr instead of the full binary image
@@ -116,6 +119,7 @@ hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, u
                             rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
 hipError_t rcc_launch_dense_runs(rcc_handle* h, const uint8_t* d_grey, int nframes, const unsigned long long* d_flat, int flat_tp,
                                  rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
+hipError_t rcc_launch_pack_records(rcc_handle* h, int nframes, int frame_offset, double* d_table, hipStream_t s);
 hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t* d_cand_count,
                            int nframes, hipStream_t s);
 hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);

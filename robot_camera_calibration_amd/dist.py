@@ -5,13 +5,21 @@ is downstream of this path), so N ranks simply own disjoint frame ranges and no 
 pixels.  The only exchange is the per-batch all-gather of fixed-size pose records so that one
 process (the ROS node's publisher, or the map builder) sees every frame's result -- the role the
 "tag_detections" topic plays between processes in the reference (corner_detections.cpp:78).
-Records are 17 doubles per frame slot (~139 KB per rank for 1024 frames): latency-bound on xGMI,
+Records are REC = 19 doubles per slot (~156 KB per rank for 1024 frames): latency-bound on xGMI,
 so it is ONE all_gather per batch, never per frame.
+
+Record layout (include/rcc.h, RCC_REC_DOUBLES): valid, global frame, id, ncorners, rvec[3], tvec[3], rms and ALL
+FOUR corners bl, br, tr, tl (x, y) -- the consumer reads all four (corner_detections.cpp:51-56).
+On a GPU the table is packed on the device by the detector itself (rcc_set_record_tables, csrc/k_records.hip) and
+handed to the collective as it is; `pack` is the host form of the same layout (CPU ranks of the gloo tests, and the
+check of the device form in the GPU tests).  librcc_dist.so (include/rcc_dist.h) is the same all-gather for C++ hosts.
 """
 import numpy as np
 import torch
 
-REC = 17  # valid, frame, id, ncorners, rvec[3], tvec[3], rms, corners bl/br/tr/tl x,y (first 6 of 8 kept) -> see pack()
+from . import abi
+
+REC = abi.RCC_REC_DOUBLES  # 19
 
 
 def shard_range(nframes, rank, world):
@@ -22,52 +30,78 @@ def shard_range(nframes, rank, world):
     return lo, hi
 
 
-def pack(dets, nslots, frame_offset=0):
-    """rcc_detection records -> (nslots, REC) float64, zero-padded; slot = frame index in the batch."""
+def pack(dets, nframes, targets_per_frame=1, frame_offset=0):
+    """rcc_detection records (ordered by frame, as detect() returns them) -> (nframes * targets_per_frame, REC)
+    float64, zero-padded; slot = frame * targets_per_frame + q for the frame's q-th record.  A frame with more
+    records than targets_per_frame, or a frame index outside the batch, is an error -- never a silent cut."""
+    nslots = nframes * targets_per_frame
     a = np.zeros((nslots, REC), np.float64)
     if len(dets) == 0:
         return a
     d = np.asarray(dets)
-    if len(d) > nslots or len(np.unique(d["frame"])) != len(d):
-        # several targets per frame (fiducials): slot = running index, capped at nslots
-        d = d[:nslots]
-        fr = np.arange(len(d))
-        a[fr, 0] = 1.0
-        a[fr, 1] = d["frame"] + frame_offset
-        a[fr, 2] = d["id"]; a[fr, 3] = d["ncorners"]; a[fr, 4:7] = d["rvec"]; a[fr, 7:10] = d["tvec"]; a[fr, 10] = d["rms"]
-        a[fr, 11:17] = d["corners"].reshape(len(d), 8)[:, :6]
-        return a
-    fr = d["frame"]
-    a[fr, 0] = 1.0
-    a[fr, 1] = fr + frame_offset
-    a[fr, 2] = d["id"]
-    a[fr, 3] = d["ncorners"]
-    a[fr, 4:7] = d["rvec"]
-    a[fr, 7:10] = d["tvec"]
-    a[fr, 10] = d["rms"]
-    a[fr, 11:17] = d["corners"].reshape(len(d), 8)[:, :6]
+    fr = np.asarray(d["frame"], np.int64)
+    if fr.min() < 0 or fr.max() >= nframes:
+        raise ValueError("record of frame %d outside the batch of %d frames" % (int(fr.max() if fr.max() >= nframes else fr.min()), nframes))
+    if np.any(np.diff(fr) < 0):
+        raise ValueError("records are not ordered by frame")
+    first = np.searchsorted(fr, fr, side="left")           # index of the frame's first record
+    q = np.arange(len(d)) - first
+    if q.max() >= targets_per_frame:
+        raise ValueError("a frame holds %d records but the table has %d slots per frame" % (int(q.max()) + 1, targets_per_frame))
+    slot = fr * targets_per_frame + q
+    a[slot, 0] = 1.0
+    a[slot, 1] = fr + frame_offset
+    a[slot, 2] = d["id"]
+    a[slot, 3] = d["ncorners"]
+    a[slot, 4:7] = d["rvec"]
+    a[slot, 7:10] = d["tvec"]
+    a[slot, 10] = d["rms"]
+    a[slot, 11:19] = np.asarray(d["corners"]).reshape(len(d), 8)
     return a
 
 
 class PoseGather:
     """One all_gather of pose records per batch.  world == 1: no collective at all."""
 
-    def __init__(self, nslots, device, world, dist_module=None, rank=0):
-        self.nslots, self.device, self.world, self.dist, self.rank = nslots, device, world, dist_module, rank
-        self.send = torch.zeros((nslots, REC), dtype=torch.float64, device=device)
-        self.recv = torch.zeros((world * nslots, REC), dtype=torch.float64, device=device) if world > 1 else None
-        self.pinned = torch.zeros((nslots, REC), dtype=torch.float64)
-        if torch.cuda.is_available() and getattr(device, "type", "cpu") == "cuda":
-            self.pinned = self.pinned.pin_memory()
+    def __init__(self, nframes, device, world, dist_module=None, rank=0, targets_per_frame=1):
+        self.nframes, self.tpf = nframes, targets_per_frame
+        self.nslots = nframes * targets_per_frame
+        self.device, self.world, self.dist, self.rank = device, world, dist_module, rank
+        on_gpu = getattr(device, "type", "cpu") == "cuda"
+        # two send tables: the detector fills one per result slot (submit/collect keeps two batches in flight)
+        self.tables = [torch.zeros((self.nslots, REC), dtype=torch.float64, device=device) for _ in range(2 if on_gpu else 1)]
+        self.recv = torch.zeros((world * self.nslots, REC), dtype=torch.float64, device=device) if world > 1 else None
+        self.attached = False
+        self.frame_offset = 0
 
-    def run(self, dets, frame_offset=0):
-        """returns the number of valid records visible to this rank after the exchange"""
+    def attach(self, detector, frame_offset=0):
+        """GPU ranks: let the detector pack its records into this gather's tables on the device"""
+        detector.set_record_tables(self.tables[0], self.tables[-1], frame_offset)
+        self.attached, self.frame_offset = True, frame_offset
+
+    def exchange(self, dets, slot=0):
+        """One step's exchange, whatever the rank is made of: the device table of result slot `slot` when a detector
+        packs it (attach), else the host records; no collective at all in a world of one.  Returns the number of valid
+        records this rank sees."""
         if self.world == 1 or self.dist is None:
             return len(dets)
-        self.pinned.numpy()[:] = pack(dets, self.nslots, frame_offset)
-        self.send.copy_(self.pinned, non_blocking=True)
-        self.dist.all_gather_into_tensor(self.recv, self.send)
+        if self.attached:
+            return self.run_table(self.tables[slot if slot < len(self.tables) else 0])
+        return self.run(dets, self.frame_offset)
+
+    def run_table(self, table):
+        """exchange a table that already sits on the device (filled by the detector); returns the number of valid
+        records visible to this rank"""
+        if self.world == 1 or self.dist is None:
+            return int((table[:, 0] > 0.5).sum().item())
+        self.dist.all_gather_into_tensor(self.recv, table)
         return int((self.recv[:, 0] > 0.5).sum().item())
 
+    def run(self, dets, frame_offset=0):
+        """host records -> table -> exchange (CPU ranks; GPU ranks use attach() + run_table())"""
+        t = self.tables[0]
+        t.copy_(torch.from_numpy(pack(dets, self.nframes, self.tpf, frame_offset)))
+        return self.run_table(t)
+
     def gathered(self):
-        return self.recv if self.recv is not None else self.send
+        return self.recv if self.recv is not None else self.tables[0]

@@ -22,6 +22,7 @@ torch.cuda.synchronize()
 det.stage_ingest(frames, B, grey)
 for _ in range(3):
     det.stage_threshold_corner(grey, B, binm, cand, cnt)
+det.time_dense(grey, B, None, cand, cnt, 3)      # the form rcc_detect_batch launches: compact threshold map
 for _ in range(3):
     det._chk(det._L.rcc_debug_calib_copy(det._h, api._ptr(grey), api._ptr(binm), B * px), "calib")
 print("frames", B, "alg bytes per dense launch", 2 * px * B, "copy bytes read", B * px, "written", B * px)

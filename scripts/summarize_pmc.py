@@ -4,7 +4,8 @@ profiles/<tag>_pmc_<kernel>.json and, for the dense pass, profiles/traffic_dense
 FETCH_SIZE / WRITE_SIZE are calibrated on a streaming copy with a known byte count and the same access width
 (k_calib_copy_x4 for the 16 B/lane band and ingest kernels, k_calib_copy_dword for the strip kernel), as
 MI355X_MICROARCH.md's HBM section prescribes.  Counter unit: KiB.
-usage: summarize_pmc.py FETCH.csv WRITE.csv NFRAMES TAG KERNEL_SUBSTRING ALG_BYTES_PER_FRAME [CALIB_KERNEL]"""
+usage: summarize_pmc.py FETCH.csv WRITE.csv NFRAMES TAG KERNEL_SUBSTRING ALG_BYTES_PER_FRAME [CALIB_KERNEL [SHORT_NAME]]
+SHORT_NAME names the outputs (profiles/<tag>_pmc_<short>.json, profiles/traffic_<short>.json); default dense / ingest."""
 import csv, json, sys, os
 fetch_csv, write_csv, nframes, tag, ksub, alg_pf = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5], float(sys.argv[6])
 calib = sys.argv[7] if len(sys.argv) > 7 else "k_calib_copy_x4"
@@ -32,7 +33,7 @@ alg = alg_pf * nframes
 out.update({"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "algorithmic_bytes_per_launch": alg,
             "traffic_over_algorithmic": (rd + wr) / alg, "hbm_bytes_per_frame": (rd + wr) / nframes})
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-short = "dense" if "dense" in kname else ("ingest" if "ingest" in kname else kname)
+short = sys.argv[8] if len(sys.argv) > 8 else ("dense" if "dense" in kname else ("ingest" if "ingest" in kname else kname))
 json.dump(out, open(os.path.join(root, "profiles", "%s_pmc_%s.json" % (tag, short)), "w"), indent=1)
 json.dump({"hbm_bytes_per_frame": out["hbm_bytes_per_frame"], "source": "%s_pmc_%s.json" % (tag, short), "kernel": kname,
            "frames_in_profiled_launch": nframes}, open(os.path.join(root, "profiles", "traffic_%s.json" % short), "w"), indent=1)

@@ -52,6 +52,26 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(built, name), "librcc_hip.so does not export %s" % name
 
 
+def test_dist_library_exports_every_declared_symbol(built):
+    """include/rcc_dist.h (librcc_dist.so: the RCCL all-gather of the record tables for C++ hosts): loads, exports every
+    declared symbol, and validates arguments before touching a device"""
+    hdr = open(os.path.join(ROOT, "include", "rcc_dist.h")).read()
+    declared = set(re.findall(r"\b(rcc_dist_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(api.DIST_EXPORTED_SYMBOLS), declared ^ set(api.DIST_EXPORTED_SYMBOLS)
+    assert os.path.exists(api.dist_library_path()), "librcc_dist.so has not been built"
+    L = C.CDLL(api.dist_library_path())
+    for name in declared:
+        assert hasattr(L, name), "librcc_dist.so does not export %s" % name
+    L.rcc_dist_create.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    h = C.c_void_p()
+    ident = (C.c_char * 128)()
+    assert L.rcc_dist_create(0, 0, ident, 0, C.byref(h)) == abi.RCC_ERR_ARG          # world < 1
+    assert L.rcc_dist_create(2, 2, ident, 0, C.byref(h)) == abi.RCC_ERR_ARG          # rank >= world
+    assert L.rcc_dist_create(0, 1, None, 0, C.byref(h)) == abi.RCC_ERR_ARG
+    assert L.rcc_dist_unique_id(None) == abi.RCC_ERR_ARG
+    assert re.search(r"#define\s+RCC_REC_DOUBLES\s+19", open(os.path.join(ROOT, "include", "rcc.h")).read()) and abi.RCC_REC_DOUBLES == 19
+
+
 def test_host_only_entry_points(built, oracle):
     assert built.rcc_abi_version() == abi.RCC_ABI_VERSION
     assert api.status_string(0) == "ok" and "capacity" in api.status_string(abi.RCC_ERR_CAPACITY)

@@ -206,3 +206,33 @@ def test_hip_fiducials_random_pose_sweep(oracle):
     assert k0 == len(dets) and worst <= 1e-4
     print("sweep: %d tags over %d frames (%d frames with fewer than %d), max pose diff %.2e" % (k0, n, partial, GX * GY, worst))
     det.close()
+
+
+@pytest.mark.gpu
+def test_record_table_multi_tag_frames():
+    """the device-packed record table (rcc_set_record_tables) with several tags per frame: slot = frame * max_targets + q,
+    equal to the host form dist.pack builds from the same records; a multi-tag frame survives the exchange whole"""
+    import torch
+    from robot_camera_calibration_amd import dist as rdist
+    cfg, fam = _cfg(api.default_config, B=3)
+    (hx, hy), centres, ids, sp = _scene(cfg)
+    det = api.Detector(cfg)
+    n = 3
+    poses = np.concatenate([synth.sample_poses(1, cfg, seed=300 + f, z_range=(0.9, 1.6), max_tilt_deg=40, half_extent_m=(hx, hy)) for f in range(n)])
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    frames[1].fill_(128)                                    # a frame without tags
+    torch.cuda.synchronize()
+    nslots = det.record_slots(n)
+    assert nslots == n * cfg.max_targets
+    tab = torch.full((nslots, rdist.REC), -1.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    det.set_record_tables(tab, None, frame_offset=50)
+    dets, _ = det.detect(frames, n)
+    assert len(dets) == 2 * GX * GY and set(dets.frame.tolist()) == {0, 2}
+    got = tab.cpu().numpy()
+    assert np.array_equal(got, rdist.pack(dets, n, cfg.max_targets, 50))
+    assert (got[cfg.max_targets:2 * cfg.max_targets] == 0).all()
+    with pytest.raises(ValueError):
+        rdist.pack(dets, n, GX * GY - 1, 50)               # too few slots per frame: an error, never a cut
+    det.close()

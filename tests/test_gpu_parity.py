@@ -497,3 +497,63 @@ def test_config4_fisheye_4k(torch_cuda, oracle):
     det.close()
     mx, found = _check_batch(torch_cuda, oracle, cfg, frames, 2)
     print("max diffs", mx)
+
+
+def test_record_tables_packed_on_device(torch_cuda):
+    """rcc_set_record_tables: the table the ranks exchange is packed on the device by the detector (csrc/k_records.hip);
+    it must equal the host form of the same layout (dist.pack) built from the records detect() returns -- every field,
+    all four corners -- for detect() and for both result slots of submit / collect"""
+    torch = torch_cuda
+    from robot_camera_calibration_amd import dist as rdist
+    n = 10
+    cfg = _make(w=640, h=480, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch, det, cfg, n, seed=31)
+    frames[4].zero_()                                       # a frame without a board: an all-zero slot
+    torch.cuda.synchronize()
+    assert det.record_slots(n) == n
+    t0 = torch.full((n, rdist.REC), -7.0, dtype=torch.float64, device="cuda:0")
+    t1 = torch.full((n, rdist.REC), -7.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    det.set_record_tables(t0, t1, frame_offset=1000)
+    dets, _ = det.detect(frames, n)
+    assert 4 not in set(dets.frame.tolist()) and len(dets) >= n - 2
+    exp = rdist.pack(dets, n, 1, 1000)
+    assert np.array_equal(t0.cpu().numpy(), exp)
+    assert (exp[dets.frame, 17:19] == dets.corners[:, 3, :]).all()
+    det.submit(frames, n); det.submit(frames, n)
+    for k in range(2):
+        d, _ = det.collect()
+        assert det.last_slot == k
+        assert np.array_equal((t0, t1)[det.last_slot].cpu().numpy(), rdist.pack(d, n, 1, 1000))
+    det.set_record_tables(None, None)
+    t0.fill_(-7.0); torch.cuda.synchronize()
+    det.detect(frames, n)
+    assert (t0.cpu().numpy() == -7.0).all()                 # switched off: the table is no longer written
+    det.close()
+
+
+def test_rccl_allgather_records_world1(torch_cuda):
+    """include/rcc_dist.h through the C ABI on the one GPU of the test box: a world of one rank, RCCL all-gather of a
+    record table (what a C++ host with one process per GPU calls once per batch)"""
+    torch = torch_cuda
+    from robot_camera_calibration_amd import dist as rdist
+    L = C.CDLL(api.dist_library_path())
+    L.rcc_dist_create.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    L.rcc_dist_allgather_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.rcc_dist_destroy.argtypes = [C.c_void_p]
+    L.rcc_dist_destroy.restype = None
+    L.rcc_dist_world.argtypes = [C.c_void_p]
+    ident = (C.c_char * 128)()
+    assert L.rcc_dist_unique_id(ident) == abi.RCC_OK
+    h = C.c_void_p()
+    assert L.rcc_dist_create(0, 1, ident, 0, C.byref(h)) == abi.RCC_OK
+    assert L.rcc_dist_world(h) == 1
+    nslots = 64
+    tab = torch.arange(nslots * rdist.REC, dtype=torch.float64, device="cuda:0").reshape(nslots, rdist.REC)
+    out = torch.zeros_like(tab)
+    torch.cuda.synchronize()
+    assert L.rcc_dist_allgather_records(h, tab.data_ptr(), nslots, out.data_ptr(), None) == abi.RCC_OK
+    torch.cuda.synchronize()
+    assert torch.equal(out, tab)
+    L.rcc_dist_destroy(h)
