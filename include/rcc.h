@@ -112,7 +112,9 @@ typedef struct rcc_config {
   /* a7 */
   int32_t reference_mode;   /* 1: truncate sub-pixel corners to int before PnP, as
                                corner_detections.cpp:53-54 does */
-  int32_t pnp_use_mfma;     /* 1: f64 MFMA for the JtJ/Jte blocks of the wave-per-target solver */
+  int32_t pnp_use_mfma;     /* 1: the 4-point tag poses (RCC_TARGET_FIDUCIAL) accumulate J^T J / J^T e with
+                               v_mfma_f64_16x16x4_f64, two targets per instruction (csrc/k_pnp_mfma.hip); 0 (default):
+                               vector FMAs, one lane per target -- the faster form, DESIGN.md section 5.  Same poses to 1e-9. */
 
   /* resources */
   int32_t device;           /* HIP device ordinal */
@@ -260,6 +262,8 @@ int rcc_set_pipeline(rcc_handle* h, int nchunks);
 /* PnP mapping: 0 = one lane per target, 1 = one wavefront per target when a target has more than
  * 8 points, -1 = automatic (same as 1). */
 int rcc_set_pnp_variant(rcc_handle* h, int variant);
+/* switches rcc_config.pnp_use_mfma of a live handle (A/B timing, tests).  Returns the previous setting. */
+int rcc_set_pnp_mfma(rcc_handle* h, int on);
 /* a4 list stage + a5 + a6 + a7 for the board: consumes the dense pass outputs, fills per-frame
  * device records (layout = rcc_frame_corners / rcc_detection), then copies to host. */
 int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, const void* d_cand,

@@ -92,6 +92,8 @@ def load_library():
     L.rcc_debug_calib_copy.restype = C.c_int
     L.rcc_last_dense_kernel.argtypes = [P]
     L.rcc_last_dense_kernel.restype = C.c_char_p
+    L.rcc_set_pnp_mfma.argtypes = [P, C.c_int]
+    L.rcc_set_pnp_mfma.restype = C.c_int
     L.rcc_set_record_tables.argtypes = [P, P, P, I]
     L.rcc_set_record_tables.restype = C.c_int
     L.rcc_record_slots.argtypes = [P, I]
@@ -114,7 +116,7 @@ EXPORTED_SYMBOLS = (
     "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_set_dense_variant",
     "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_set_dense_skip", "rcc_set_keep_binary", "rcc_set_fuse_grid_pnp", "rcc_detect_batch_submit", "rcc_detect_batch_collect", "rcc_debug_overlap", "rcc_set_pipeline", "rcc_time_copy", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
     "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch", "rcc_debug_calib_copy",
-    "rcc_debug_pnp_probe", "rcc_set_record_tables", "rcc_record_slots", "rcc_last_dense_kernel",
+    "rcc_debug_pnp_probe", "rcc_set_record_tables", "rcc_record_slots", "rcc_last_dense_kernel", "rcc_set_pnp_mfma",
 )
 # include/rcc_dist.h (librcc_dist.so: the RCCL all-gather of the record tables for non-Python hosts)
 DIST_EXPORTED_SYMBOLS = ("rcc_dist_unique_id", "rcc_dist_create", "rcc_dist_destroy", "rcc_dist_rank", "rcc_dist_world",
@@ -334,6 +336,10 @@ class Detector:
     def set_pipeline(self, nchunks):
         """chunks of detect()'s two-stream pipeline (0/1: single pass, per-stage timings available)"""
         return self._L.rcc_set_pipeline(self._h, int(nchunks))
+
+    def set_pnp_mfma(self, on):
+        """1: 4-point tag poses accumulate their normal equations on the matrix cores (cfg.pnp_use_mfma); returns the previous setting"""
+        return self._L.rcc_set_pnp_mfma(self._h, int(on))
 
     def set_pnp_variant(self, v):
         return self._L.rcc_set_pnp_variant(self._h, int(v))

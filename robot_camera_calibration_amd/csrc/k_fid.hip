@@ -544,6 +544,7 @@ hipError_t rcc_launch_pnp_tags(rcc_handle* h, int nframes, hipStream_t s)
   cam.model = h->undist ? RCC_DIST_NONE : c.dist_model;
   cam.solver = h->pnp_solver;
   const int total = nframes * c.max_targets;
+  if (h->pnp_use_mfma) return rcc_launch_pnp_tags_mfma(h, nframes, cam, s);   // J^T J / J^T e on the matrix cores (k_pnp_mfma.hip)
   hipLaunchKernelGGL(k_pnp_tags, dim3((total + 63) / 64), dim3(64), 0, s, h->d_det, h->d_ndet, nframes, c.max_targets,
                      c.tag_size, c.reference_mode, cam);
   return hipGetLastError();

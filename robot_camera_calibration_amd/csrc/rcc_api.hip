@@ -152,6 +152,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->pnp_variant = -1;
   h->kept_cap = (cfg->target_kind == RCC_TARGET_FIDUCIAL) ? RCC_MAX_KEPT_FIDUCIAL : RCC_MAX_KEPT;
   h->pnp_solver = 1;
+  h->pnp_use_mfma = cfg->pnp_use_mfma ? 1 : 0;
   if (const char* e = getenv("RCC_PNP_SOLVER")) h->pnp_solver = atoi(e);
   h->sp.win = cfg->subpix_win;
   h->sp.max_iter = cfg->subpix_max_iter;
@@ -263,6 +264,13 @@ int rcc_set_pnp_variant(rcc_handle* h, int variant)
   if (!h) return RCC_ERR_ARG;
   int p = h->pnp_variant;
   h->pnp_variant = variant;
+  return p;
+}
+int rcc_set_pnp_mfma(rcc_handle* h, int on)
+{
+  if (!h) return RCC_ERR_ARG;
+  int p = h->pnp_use_mfma;
+  h->pnp_use_mfma = on ? 1 : 0;
   return p;
 }
 int rcc_set_ingest_variant(rcc_handle* h, int variant)

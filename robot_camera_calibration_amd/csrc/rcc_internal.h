@@ -105,6 +105,7 @@ struct rcc_handle {
   int dense_skip;           // 1: the fast dense kernel may skip flat wave-rows (exact); 0: never (A/B, tests)
   int pnp_variant;          // -1 auto, 0 lane per target, 1 wavefront per target (board)
   int pnp_solver;           // 0 eigen, 1 Cholesky (default)
+  int pnp_use_mfma;         // cfg.pnp_use_mfma / rcc_set_pnp_mfma: 4-point tag poses accumulate J^T J, J^T e on the matrix cores
   int kept_cap;             // stride of the per-frame suppressed-list buffers: 256 (board) or 2048 (fiducials)
   uint64_t* d_family;       // fiducial family table (device copy)
   int pnp_wave_hint;        // set per rcc_solve_pnp_batch call: max points per target > 8
@@ -128,6 +129,7 @@ hipError_t rcc_launch_expand_bin(rcc_handle* h, const uint8_t* d_grey, int nfram
 hipError_t rcc_launch_fid(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_tags(rcc_handle* h, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s);
+hipError_t rcc_launch_pnp_tags_mfma(rcc_handle* h, int nframes, rcc_cam cam, hipStream_t s);
 hipError_t rcc_launch_grid_pnp(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s);
 bool rcc_grid_pnp_applicable(const rcc_handle* h);
 hipError_t rcc_launch_pnp_generic(rcc_handle* h, const double* d_obj, const double* d_img,

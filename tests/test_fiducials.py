@@ -236,3 +236,47 @@ def test_record_table_multi_tag_frames():
     with pytest.raises(ValueError):
         rdist.pack(dets, n, GX * GY - 1, 50)               # too few slots per frame: an error, never a cut
     det.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reference_mode", [0, 1])
+def test_tag_pose_mfma_form_matches_vector_form_and_oracle(oracle, reference_mode):
+    """rcc_config.pnp_use_mfma (BASELINE.json north_star: MFMA for the batched JtJ / Jtr blocks; configs[4]): the 4-point
+    tag poses with their normal equations accumulated by v_mfma_f64_16x16x4_f64, two targets per instruction, against the
+    vector form (default) and against the oracle (bar 1e-4) -- sub-pixel corners and int-truncated ones
+    (corner_detections.cpp:53-54).  The flag is honoured both from the configuration and from rcc_set_pnp_mfma."""
+    import torch
+    cfg, fam = _cfg(api.default_config, B=3)
+    cfg.reference_mode = reference_mode
+    (hx, hy), centres, ids, sp = _scene(cfg)
+    n = 3
+    poses = np.concatenate([synth.sample_poses(1, cfg, seed=400 + f, z_range=(0.9, 1.6), max_tilt_deg=40, half_extent_m=(hx, hy)) for f in range(n)])
+    det = api.Detector(cfg)
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    torch.cuda.synchronize()
+    v, _ = det.detect(frames, n)
+    assert det.set_pnp_mfma(1) == 0
+    m, _ = det.detect(frames, n)
+    assert det.set_pnp_mfma(0) == 1
+    det.close()
+    cfg2 = api.clone_config(cfg)
+    cfg2.pnp_use_mfma = 1
+    det2 = api.Detector(cfg2)
+    m2, _ = det2.detect(frames, n)
+    det2.close()
+    assert len(v) == len(m) == len(m2) == n * GX * GY
+    assert (v.id == m.id).all() and (v.frame == m.frame).all() and (v.pnp_status == m.pnp_status).all() and (m.pnp_status == 0).all()
+    assert m.tobytes() == m2.tobytes()
+    assert np.abs(v.rvec - m.rvec).max() <= 1e-6 and np.abs(v.tvec - m.tvec).max() <= 1e-6 and np.abs(v.rms - m.rms).max() <= 1e-6   # measured 1.6e-8 over 24 456 tags; bar 1e-4
+    assert (v.pnp_iters == m.pnp_iters).mean() >= 0.95
+    host = frames.cpu().numpy()
+    ctx = oracle.Context(cfg)
+    k0 = 0
+    for f in range(n):
+        k, odet, ofc = ctx.detect(host[f], f)
+        for q in range(k):
+            a, b = m[k0 + q], odet[q]
+            assert a.id == b.id
+            assert np.abs(a.rvec - np.array(list(b.rvec))).max() <= 1e-4 and np.abs(a.tvec - np.array(list(b.tvec))).max() <= 1e-4
+        k0 += k
