@@ -87,7 +87,8 @@ typedef struct rcc_config {
   double D[8];
 
   /* a3 adaptive threshold (apriltag tile min/max form) */
-  int32_t thr_min_contrast; /* 5 */
+  int32_t thr_min_contrast; /* a tile whose 3x3-dilated max - min is below this is "flat" (127).  Default 32: apriltag's own
+                               5 (appendix B.3) turns the sensor noise of flat areas into salt and pepper */
 
   /* a4 corner extraction */
   int32_t harris_thresh;    /* accept R >= this (integer Harris response) */
@@ -236,32 +237,12 @@ int rcc_stage_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void*
  *   d_cand_count nframes int32 (true count, may exceed max_candidates) */
 int rcc_stage_threshold_corner(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_bin,
                                void* d_cand, void* d_cand_count, void* stream);
-/* variant selector for the dense pass: 0 = generic LDS-staged kernel, 1 = row-marching fast kernel
- * (needs width % 64 == 0); -1 = automatic.  Returns the previous value. */
-int rcc_set_dense_variant(rcc_handle* h, int variant);
-int rcc_set_ingest_variant(rcc_handle* h, int variant);
-/* fast dense variant only: 1 (default) lets it skip the corner stages on wave-rows whose tiles are all
- * low-contrast (exact: see k_dense_fast.hip), 0 disables the skip.  Returns the previous value. */
-int rcc_set_dense_skip(rcc_handle* h, int on);
 /* rcc_detect_batch and the binary image: the stages after the threshold+corner pass read it at 16 ring points per
  * corner only, so by default the pass leaves it as a compact map (one byte per 4x4 tile: level or "flat") -- 1/16 of
  * the output bytes, same decisions -- and rcc_debug_fetch_images expands it on demand.  on = 1 makes
  * rcc_detect_batch materialise the full binary image (as rcc_stage_threshold_corner always does).  Returns the
  * previous setting. */
 int rcc_set_keep_binary(rcc_handle* h, int on);
-/* 1 (default): the checkerboard path runs lattice indexing and the pose solve of a frame in one kernel (one
- * wavefront per frame); 0: as two kernels.  Same results.  Returns the previous setting. */
-int rcc_set_fuse_grid_pnp(rcc_handle* h, int on);
-/* rcc_detect_batch pipeline: n > 1 cuts a batch into n chunks (at least 64 frames each) that alternate over two
- * internal streams, so that the per-frame dependency chains of target identification and pose run under the
- * bandwidth-bound passes of the next chunk; 0 or 1 = one pass on one stream (per-stage times of rcc_last_timings
- * are recorded only then; the pipelined path reports -1).  Results are identical.  Default 1: on MI355X the
- * chunked form measured 7-25 % slower at 1024 x 1080p (kernels of different streams do not overlap usefully once
- * each fills the chip).  Returns the previous setting. */
-int rcc_set_pipeline(rcc_handle* h, int nchunks);
-/* PnP mapping: 0 = one lane per target, 1 = one wavefront per target when a target has more than
- * 8 points, -1 = automatic (same as 1). */
-int rcc_set_pnp_variant(rcc_handle* h, int variant);
 /* switches rcc_config.pnp_use_mfma of a live handle (A/B timing, tests).  Returns the previous setting. */
 int rcc_set_pnp_mfma(rcc_handle* h, int on);
 /* a4 list stage + a5 + a6 + a7 for the board: consumes the dense pass outputs, fills per-frame
@@ -270,45 +251,8 @@ int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, cons
                       const void* d_cand_count, int32_t nframes, rcc_detection* det, int32_t* ndet,
                       rcc_frame_corners* corners, void* stream);
 
-/* timings of the last rcc_detect_batch / stage call, milliseconds, measured with HIP events on the
- * stream the kernels were launched on: [0] ingest, [1] dense threshold+corner, [2] list+subpix+grid,
- * [3] pnp, [4] d2h (with rcc_set_fuse_grid_pnp(1), the default for checkerboards, the grid stage runs inside the
- * pose kernel and is counted in [3]).  Returns the number of slots written. */
-int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n);
-/* name(s) of the kernel(s) the handle's last threshold + corner launch used, spelled as rocprofv3's kernel trace prints
- * them (bench.py quotes it beside the roofline figure, so that the figure can be matched with profiles/) */
-const char* rcc_last_dense_kernel(const rcc_handle* h);
-/* Launch the dense pass `reps` times back to back and return the mean kernel time in ms measured
- * with HIP events on the launch stream (bench.py's roofline leg).  d_bin == NULL times the form
- * rcc_detect_batch runs: binary image left as the compact threshold map in the handle (nframes <= batch_capacity). */
-int rcc_time_dense(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_bin, void* d_cand,
-                   void* d_cand_count, int32_t reps, float* mean_ms);
-int rcc_time_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey,
-                    int32_t reps, float* mean_ms);
-
-/* test taps: copy the intermediate lists / images of the handle's last rcc_detect_batch to host
- * memory (any pointer may be NULL).  pre/kept: nframes*256 entries {int16 x, int16 y, int32 score};
- * pre_xy/kept_xy: nframes*256*2 doubles; cand: nframes*max_candidates entries. */
-int rcc_debug_fetch_lists(rcc_handle* h, int32_t nframes, void* pre, int32_t* npre, double* pre_xy,
-                          void* kept, double* kept_xy);
-int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin, void* cand,
-                           int32_t* cand_count);
-
-/* experiment (scratch/t_overlap.py): the ingest pass and the threshold+corner pass over independent buffers, back to
- * back on one stream (mode 0) or launched together on two streams (mode 1); mean milliseconds per pair. */
-int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,
-                      void* d_cand, void* d_cand_count, int32_t mode, int32_t reps, float* mean_ms);
-
-/* measurement aid: mean milliseconds of `reps` plain streaming copies (16 B per lane) of nbytes between two device
- * buffers (16-byte aligned, nbytes a multiple of 16), timed with HIP events on the handle's stream.  bench.py
- * quotes it beside the threshold+corner pass, which moves the same bytes. */
-int rcc_time_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes, int32_t reps, float* mean_ms);
-
-/* profiling aid: streaming copy with the dense pass's access width (4 B per lane), device pointers */
-int rcc_debug_calib_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes);
-/* test tap: intermediates of one PnP solve (host pointers), out[59] */
-int rcc_debug_pnp_probe(rcc_handle* h, const double* obj, const double* img, int32_t n, const double* K,
-                        const double* D, int32_t dist_model, double* out);
+/* Test taps, HIP-event timers and A/B switches between bit-identical kernel variants are NOT part of this boundary:
+ * they are declared in include/rcc_debug.h (test + measurement infrastructure). */
 
 /* ---- synthetic camera (stands where rviz_simulator's missing camera.h was meant to be,
  *      rviz_simulator/include/rviz_simulator/target.h:40) --------------------- */

@@ -1,0 +1,82 @@
+/*
+ * rcc_debug.h -- test taps, HIP-event timers and A/B switches of librcc_hip.so.  NOT part of the drop-in boundary
+ * (include/rcc.h): nothing here stands in for an interface of the reference, and a host built on rcc.h never needs it.
+ *
+ * Why the symbols are still in the shipped library: the parity tests (tests/) compare the HIP path with the oracle
+ * STAGE BY STAGE through the C ABI, so they need the intermediate images and lists (rcc_debug_fetch_*), and bench.py
+ * needs per-kernel HIP-event times for its roofline leg (rcc_time_*).  Every entry point here is read-only with
+ * respect to results: taps copy buffers out, timers launch a pass repeatedly, and each switch selects between kernel
+ * variants that are tested bit-identical (tests/test_gpu_parity.py::test_kernel_variants_bit_identical).
+ *
+ * What is NOT in the shipped library: anything that can change a result or exists only for a one-off experiment --
+ * environment-variable knobs (RCC_DENSE_MEMONLY runs a pass's data movement without its arithmetic: wrong results;
+ * RCC_DENSE_NSEG, RCC_DENSE_FCHUNK, RCC_RUNS_NSEG, RCC_INGEST_FPB, RCC_PNP_SOLVER) and rcc_debug_overlap.  Those are
+ * compiled only with -DRCC_EXPERIMENTS (make -C robot_camera_calibration_amd/csrc EXPERIMENTS=1 builds
+ * librcc_hip_exp.so beside the product library); the default build reads no environment variable at all.
+ */
+#ifndef RCC_DEBUG_H_
+#define RCC_DEBUG_H_
+
+#include "rcc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- A/B switches between bit-identical variants (each returns the previous setting) -------------------------------- */
+/* threshold + corner pass: 0 = generic LDS tiles (any geometry), 1 = band kernel (k_dense_band.hip), 2 = strip march
+ * (k_dense_fast.hip), 3 = band sweep + corner kernel on the active rows (k_dense_runs.hip); -1 = automatic (1 where the
+ * geometry allows it, else 2, else 0) */
+int rcc_set_dense_variant(rcc_handle* h, int variant);
+int rcc_set_ingest_variant(rcc_handle* h, int variant);
+/* 1 (default): the marching dense kernels skip the corner stages on wave-rows whose tiles are all flat (exact); 0: never */
+int rcc_set_dense_skip(rcc_handle* h, int on);
+/* 1 (default): the checkerboard path runs lattice indexing and the pose solve of a frame in one kernel; 0: two kernels */
+int rcc_set_fuse_grid_pnp(rcc_handle* h, int on);
+/* n > 1: cut each batch into n chunks (>= 64 frames) alternating over two internal streams; default 1 (a single pass is
+ * faster at every size measured on MI355X: DESIGN.md section 5).  Per-stage timings exist only for n <= 1. */
+int rcc_set_pipeline(rcc_handle* h, int nchunks);
+/* PnP mapping: 0 = one lane per target, 1 = one wavefront per target with more than 8 points, -1 = automatic (= 1) */
+int rcc_set_pnp_variant(rcc_handle* h, int variant);
+
+/* ---- timers (HIP events on the launch stream) ------------------------------------------------------------------------ */
+/* stage times of the last synchronous rcc_detect_batch / stage call, ms: [0] ingest, [1] threshold+corner,
+ * [2] list + sub-pixel (+ grid when not fused), [3] pose (+ grid when fused), [4] d2h.  Returns the slots written. */
+int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n);
+/* name(s) of the kernel(s) the last threshold + corner launch used, as rocprofv3's kernel trace prints them */
+const char* rcc_last_dense_kernel(const rcc_handle* h);
+/* mean ms of `reps` back-to-back launches of the threshold + corner pass.  d_bin == NULL: the form rcc_detect_batch
+ * launches (binary image left as the compact threshold map in the handle; nframes <= batch_capacity) */
+int rcc_time_dense(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_bin, void* d_cand,
+                   void* d_cand_count, int32_t reps, float* mean_ms);
+int rcc_time_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey,
+                    int32_t reps, float* mean_ms);
+/* mean ms of `reps` plain streaming copies (16 B per lane, four loads in flight) of nbytes between two device buffers
+ * (16-byte aligned, nbytes a multiple of 16): the yardstick bench.py quotes beside the bandwidth-bound passes */
+int rcc_time_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes, int32_t reps, float* mean_ms);
+/* counter calibration for the PMC passes: one dword-per-lane copy and one 16 B-per-lane copy of a known byte count */
+int rcc_debug_calib_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes);
+
+/* ---- test taps (host pointers; any may be NULL) ---------------------------------------------------------------------- */
+/* intermediate lists / images of the handle's last rcc_detect_batch.  pre / kept: nframes x 256 (2048 for fiducials)
+ * entries {int16 x, int16 y, int32 score}; pre_xy / kept_xy: the same x 2 doubles; cand: nframes x max_candidates.
+ * `bin` is expanded from the compact threshold map on demand. */
+int rcc_debug_fetch_lists(rcc_handle* h, int32_t nframes, void* pre, int32_t* npre, double* pre_xy,
+                          void* kept, double* kept_xy);
+int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin, void* cand,
+                           int32_t* cand_count);
+/* intermediates of one PnP solve: out[59] = H[9], initial pose[6], JtJ[36], Jte[6], |e|^2, status * 10 + ok */
+int rcc_debug_pnp_probe(rcc_handle* h, const double* obj, const double* img, int32_t n, const double* K,
+                        const double* D, int32_t dist_model, double* out);
+
+#ifdef RCC_EXPERIMENTS
+/* experiment (scratch/t_overlap.py): the ingest pass and the threshold+corner pass over independent buffers, back to
+ * back on one stream (mode 0) or launched together on two streams (mode 1); mean milliseconds per pair. */
+int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,
+                      void* d_cand, void* d_cand_count, int32_t mode, int32_t reps, float* mean_ms);
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCC_DEBUG_H_ */

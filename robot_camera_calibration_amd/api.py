@@ -109,14 +109,19 @@ def load_library():
     return L
 
 
-# every symbol include/rcc.h declares (the CPU-side test checks the library exports them all)
+# every symbol include/rcc.h declares -- the drop-in boundary (the CPU-side test checks the library exports them all)
 EXPORTED_SYMBOLS = (
     "rcc_default_config", "rcc_create", "rcc_destroy", "rcc_status_string", "rcc_last_device_error",
-    "rcc_abi_version", "rcc_detect_batch", "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch",
-    "rcc_rodrigues_m2v_batch", "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_set_dense_variant",
-    "rcc_set_ingest_variant", "rcc_set_pnp_variant", "rcc_set_dense_skip", "rcc_set_keep_binary", "rcc_set_fuse_grid_pnp", "rcc_detect_batch_submit", "rcc_detect_batch_collect", "rcc_debug_overlap", "rcc_set_pipeline", "rcc_time_copy", "rcc_stage_targets", "rcc_last_timings", "rcc_time_dense", "rcc_time_ingest",
-    "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_synth_render_batch", "rcc_debug_calib_copy",
-    "rcc_debug_pnp_probe", "rcc_set_record_tables", "rcc_record_slots", "rcc_last_dense_kernel", "rcc_set_pnp_mfma",
+    "rcc_abi_version", "rcc_detect_batch", "rcc_detect_batch_submit", "rcc_detect_batch_collect",
+    "rcc_solve_pnp_batch", "rcc_rodrigues_v2m_batch", "rcc_rodrigues_m2v_batch",
+    "rcc_stage_ingest", "rcc_stage_threshold_corner", "rcc_stage_targets",
+    "rcc_set_keep_binary", "rcc_set_pnp_mfma", "rcc_set_record_tables", "rcc_record_slots", "rcc_synth_render_batch",
+)
+# include/rcc_debug.h: test taps, timers, A/B switches between bit-identical variants (not part of the boundary)
+DEBUG_EXPORTED_SYMBOLS = (
+    "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_set_dense_skip", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline",
+    "rcc_set_pnp_variant", "rcc_last_timings", "rcc_last_dense_kernel", "rcc_time_dense", "rcc_time_ingest", "rcc_time_copy",
+    "rcc_debug_calib_copy", "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_debug_pnp_probe",
 )
 # include/rcc_dist.h (librcc_dist.so: the RCCL all-gather of the record tables for non-Python hosts)
 DIST_EXPORTED_SYMBOLS = ("rcc_dist_unique_id", "rcc_dist_create", "rcc_dist_destroy", "rcc_dist_rank", "rcc_dist_world",

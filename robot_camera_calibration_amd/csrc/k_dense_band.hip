@@ -83,7 +83,11 @@ static void launch_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8
                         int nbands, int nseg, int seg_tiles, int allow_skip, hipStream_t s)
 {
   const rcc_config& c = h->cfg;
+#ifdef RCC_EXPERIMENTS
   static const int fc_env = getenv("RCC_DENSE_FCHUNK") ? atoi(getenv("RCC_DENSE_FCHUNK")) : 0;
+#else
+  const int fc_env = 0;
+#endif
   const int fchunk = fc_env > 0 ? fc_env : (nframes >= 1024 ? 16 : nframes >= 64 ? nframes / 64 : 1);   // frames per chunk (BAND_JOB)
   const long long njobs = (long long)nbands * nseg * ((nframes + 8 * fchunk - 1) / (8 * fchunk)) * 8 * fchunk;
   const int tp = rcc_flat_tp(c.height);
@@ -110,7 +114,11 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
   const rcc_config& c = h->cfg;
   const int w = c.width, ht = c.height, th = ht >> 2;
   const int nbands = (w + BAND_W - 1) / BAND_W;
-  static const int memonly = getenv("RCC_DENSE_MEMONLY") ? atoi(getenv("RCC_DENSE_MEMONLY")) : 0;
+#ifdef RCC_EXPERIMENTS
+  static const int memonly = getenv("RCC_DENSE_MEMONLY") ? atoi(getenv("RCC_DENSE_MEMONLY")) : 0;   // data movement only: WRONG results
+#else
+  const int memonly = 0;
+#endif
   const bool narrow = (nbands == 1) && (w <= 2048);
   const bool thr = h->want_thr && h->d_thr && !memonly;
   // Segments per frame.  A job (one workgroup marching its segment) is a chain that takes as long alone as beside two
@@ -134,7 +142,11 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
       if (waste <= best * 1.02) { if (waste < best) best = waste; nseg = n; }
     }
   }
+#ifdef RCC_EXPERIMENTS
   static const int nseg_env = getenv("RCC_DENSE_NSEG") ? atoi(getenv("RCC_DENSE_NSEG")) : 0;
+#else
+  const int nseg_env = 0;
+#endif
   if (nseg_env > 0) nseg = nseg_env;
   const int seg_tiles = (th + nseg - 1) / nseg;
   nseg = (th + seg_tiles - 1) / seg_tiles;
@@ -158,8 +170,10 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
     if (e != hipSuccess) return e;
     return rcc_launch_dense_runs(h, d_grey, nframes, h->d_flat, tp, d_cand, d_cand_count, s);
   }
-  if (memonly) { h->dense_kernel = "k_dense_band<1, 0, 9, false>"; launch_band<1, 0, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
-  else if (thr && narrow) { h->dense_kernel = "k_dense_band_occ6<2, 1, 8>"; launch_band<2, 1, 8>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
+#ifdef RCC_EXPERIMENTS
+  if (memonly) { h->dense_kernel = "k_dense_band<1, 0, 9, false>"; launch_band<1, 0, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); return hipGetLastError(); }
+#endif
+  if (thr && narrow) { h->dense_kernel = "k_dense_band_occ6<2, 1, 8>"; launch_band<2, 1, 8>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
   else if (thr) { h->dense_kernel = "k_dense_band_occ6<2, 1, 9>"; launch_band<2, 1, 9>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
   else if (narrow) { h->dense_kernel = "k_dense_band<0, 1, 8, false>"; launch_band<0, 1, 8>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }
   else { h->dense_kernel = "k_dense_band<0, 1, 9, false>"; launch_band<0, 1, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }

@@ -182,11 +182,13 @@ hipError_t rcc_launch_dense_march(rcc_handle* h, const uint8_t* d_grey, int nfra
   const int allow_skip = rcc_dense_allow_skip(h);
   const long long njobs = (long long)nstrips * nseg * nframes;
   const int blocks = (int)((njobs + 3) / 4);
-  static const int memonly = getenv("RCC_DENSE_MEMONLY") ? atoi(getenv("RCC_DENSE_MEMONLY")) : 0;
+#ifdef RCC_EXPERIMENTS
+  static const int memonly = getenv("RCC_DENSE_MEMONLY") ? atoi(getenv("RCC_DENSE_MEMONLY")) : 0;   // data movement only: WRONG results
   if (memonly)
     hipLaunchKernelGGL(k_dense_march<1>, dim3(blocks), dim3(256), 0, s, d_grey, w, ht, nstrips, nseg, seg_tiles, nframes,
                        c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
   else
+#endif
     hipLaunchKernelGGL(k_dense_march<0>, dim3(blocks), dim3(256), 0, s, d_grey, w, ht, nstrips, nseg, seg_tiles, nframes,
                        c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_bin, d_cand, d_cand_count);
   return hipGetLastError();

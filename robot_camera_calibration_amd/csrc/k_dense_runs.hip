@@ -132,7 +132,11 @@ hipError_t rcc_launch_dense_runs(rcc_handle* h, const uint8_t* d_grey, int nfram
   const rcc_config& c = h->cfg;
   const int w = c.width, ht = c.height, th = ht >> 2;
   const int nbands = (w + RCC_BAND_W - 1) / RCC_BAND_W;
+#ifdef RCC_EXPERIMENTS
   static const int nseg_env = getenv("RCC_RUNS_NSEG") ? atoi(getenv("RCC_RUNS_NSEG")) : 0;
+#else
+  const int nseg_env = 0;
+#endif
   int nseg = nseg_env > 0 ? nseg_env : rcc_dense_runs_segments(th);
   int seg_tiles = (th + nseg - 1) / nseg;
   if (seg_tiles > RUNS_MAX_SEG) { seg_tiles = RUNS_MAX_SEG; }

@@ -154,7 +154,11 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
                          ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0);
   if (variant < 0) variant = staged_ok ? 1 : 0;
   if (variant == 1 && staged_ok) {
+#ifdef RCC_EXPERIMENTS
     static const int fpb_max = getenv("RCC_INGEST_FPB") ? atoi(getenv("RCC_INGEST_FPB")) : 32;
+#else
+    const int fpb_max = 32;
+#endif
     int fpb = fpb_max;
     const int tiles = ((w + ST_TW - 1) / ST_TW) * ((ht + ST_TH - 1) / ST_TH);
     while (fpb > 2 && (int64_t)tiles * ((nframes + fpb - 1) / fpb) < 4096) fpb >>= 1;

@@ -14,6 +14,7 @@
 #include <new>
 #include <vector>
 #include "rcc_internal.h"
+#include "../../include/rcc_debug.h"
 #include "pnp_core.h"
 
 #define HIPCHK(h, expr)                                                                   \
@@ -153,7 +154,9 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->kept_cap = (cfg->target_kind == RCC_TARGET_FIDUCIAL) ? RCC_MAX_KEPT_FIDUCIAL : RCC_MAX_KEPT;
   h->pnp_solver = 1;
   h->pnp_use_mfma = cfg->pnp_use_mfma ? 1 : 0;
+#ifdef RCC_EXPERIMENTS
   if (const char* e = getenv("RCC_PNP_SOLVER")) h->pnp_solver = atoi(e);
+#endif
   h->sp.win = cfg->subpix_win;
   h->sp.max_iter = cfg->subpix_max_iter;
   h->sp.eps2 = cfg->subpix_eps * cfg->subpix_eps;
@@ -173,7 +176,8 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   for (auto& ps : h->pstream) if (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   for (auto& e : h->pev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   ALLOC(h->d_grey, B * px);
-  ALLOC(h->d_bin, B * px);
+  // d_bin (the full {0,127,255} image, B * px bytes) is allocated on first need (ensure_bin): the default detect path keeps
+  // the binary image as the compact threshold map d_thr and never touches it
   ALLOC(h->d_thr, B * (size_t)((cfg->width + RCC_BAND_W - 1) / RCC_BAND_W) * (size_t)((cfg->height + 3) >> 2) * RCC_THR_PITCH);
   ALLOC(h->d_cand, B * (size_t)cfg->max_candidates * sizeof(rcc_cand));
   ALLOC(h->d_cand_count, B * sizeof(int32_t));
@@ -243,6 +247,22 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   }
   *out = h;
   return RCC_OK;
+}
+
+// the handle's own full binary image: needed when a batch's binary image is not left as the compact threshold map
+static int ensure_bin(rcc_handle* h)
+{
+  if (h->d_bin) return RCC_OK;
+  const size_t bytes = (size_t)h->cfg.batch_capacity * h->cfg.width * h->cfg.height;
+  hipError_t e = hipMalloc((void**)&h->d_bin, bytes);
+  if (e != hipSuccess) { h->d_bin = nullptr; return e == hipErrorOutOfMemory ? RCC_ERR_NOMEM : RCC_ERR_DEVICE; }
+  return RCC_OK;
+}
+// will rcc_launch_dense (with want_thr set) write d_thr instead of a full image?  (mirrors its variant choice)
+static bool detect_needs_bin(const rcc_handle* h)
+{
+  const bool band_variant = h->dense_variant < 0 || h->dense_variant == 1 || h->dense_variant == 3;
+  return h->keep_bin || !band_variant || !rcc_dense_band_supported(h, h->d_grey, nullptr);
 }
 
 int rcc_set_dense_variant(rcc_handle* h, int variant)
@@ -323,7 +343,10 @@ int rcc_time_dense(rcc_handle* h, const void* d_grey, int32_t nframes, void* d_b
   hipStream_t s = h->stream;
   // the count reset (a tiny memset) is part of every launch of the pass; it stays inside
   h->want_thr = d_bin ? 0 : 1;      // d_bin == NULL: the form rcc_detect_batch runs (compact threshold map in the handle)
-  if (!d_bin) d_bin = h->d_bin;
+  if (!d_bin) {
+    if (detect_needs_bin(h)) { int r = ensure_bin(h); if (r != RCC_OK) return r; }
+    d_bin = h->d_bin;
+  }
   HIPCHK(h, hipEventRecord(h->ev[6], s));
   for (int r = 0; r < reps; ++r)
     HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey, nframes, (uint8_t*)d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, s));
@@ -412,7 +435,8 @@ static rcc_handle handle_view(const rcc_handle* h, int f0)
 {
   rcc_handle v = *h;
   const size_t o = (size_t)f0, px = (size_t)h->cfg.width * h->cfg.height;
-  v.d_grey += o * px; v.d_bin += o * px;
+  v.d_grey += o * px;
+  if (v.d_bin) v.d_bin += o * px;
   v.d_thr += o * (size_t)((h->cfg.width + RCC_BAND_W - 1) / RCC_BAND_W) * (size_t)((h->cfg.height + 3) >> 2) * RCC_THR_PITCH;
   v.d_cand += o * (size_t)h->cfg.max_candidates; v.d_cand_count += o;
   v.d_pre += o * (size_t)h->kept_cap; v.d_npre += o; v.d_pre_xy += o * (size_t)h->kept_cap * 2;
@@ -445,6 +469,7 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
   if (nframes == 0) return RCC_OK;
   if (h->sub_head != h->sub_tail) return RCC_ERR_STATE;              // submissions outstanding: collect them first
   HIPCHK(h, hipSetDevice(h->device));
+  if (detect_needs_bin(h)) { int rb = ensure_bin(h); if (rb != RCC_OK) return rb; }
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const uint8_t* d_frames = (const uint8_t*)frames;
   if (frames_mem == RCC_MEM_HOST) {
@@ -520,6 +545,10 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   if (h->sub_head - h->sub_tail >= 2) return RCC_ERR_STATE;          // both result slots are in flight
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  // every submission shares the handle's one set of device buffers, so outstanding submissions must be ordered by ONE
+  // stream: a second stream while a batch is in flight would let two batches race on them
+  if (h->sub_head != h->sub_tail && h->sub_stream[(h->sub_head - 1) & 1u] != s) return RCC_ERR_STATE;
+  if (detect_needs_bin(h)) { int rb = ensure_bin(h); if (rb != RCC_OK) return rb; }
   const int slot = (int)(h->sub_head & 1u);
   const uint8_t* d_frames = (const uint8_t*)frames;
   if (frames_mem == RCC_MEM_HOST) {
@@ -645,6 +674,7 @@ int rcc_debug_fetch_images(rcc_handle* h, int32_t nframes, void* grey, void* bin
   const size_t n = (size_t)nframes, px = (size_t)h->cfg.width * h->cfg.height;
   if (grey) HIPCHK(h, hipMemcpy(grey, h->d_grey, n * px, hipMemcpyDeviceToHost));
   if (bin) {
+    { int rb = ensure_bin(h); if (rb != RCC_OK) return rb; }
     if (h->bin_from_thr) {
       HIPCHK(h, rcc_launch_expand_bin(h, h->d_grey, nframes, h->d_bin, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -685,6 +715,7 @@ int rcc_time_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes,
   return RCC_OK;
 }
 
+#ifdef RCC_EXPERIMENTS
 // experiment: do the ingest pass (bandwidth-bound) and the threshold+corner pass (issue-bound) overlap when they are
 // launched on two streams over independent buffers?  mode 0: back to back on one stream; 1: concurrently.
 int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,
@@ -693,6 +724,7 @@ int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void
   if (!h || !d_frames || !d_grey_out || !d_grey_in || !d_cand || !d_cand_count || nframes < 1 || reps < 1 || !mean_ms) return RCC_ERR_ARG;
   if (nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
   HIPCHK(h, hipSetDevice(h->device));
+  if (detect_needs_bin(h)) { int rb = ensure_bin(h); if (rb != RCC_OK) return rb; }
   hipStream_t s = h->stream, a = h->pstream[0], b = h->pstream[1];
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipEventRecord(h->ev[6], s));
@@ -722,6 +754,8 @@ int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void
   *mean_ms = ms / (float)reps;
   return RCC_OK;
 }
+
+#endif  // RCC_EXPERIMENTS
 
 // ---- solvePnP / Rodrigues drop-ins -----------------------------------------------------------------
 static int ensure_pnp_buf(rcc_handle* h, size_t bytes)

@@ -118,6 +118,7 @@ struct rcc_handle {
 hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes, uint8_t* d_grey, hipStream_t s);
 hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
                             rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
+bool rcc_dense_band_supported(const rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin);
 hipError_t rcc_launch_dense_runs(rcc_handle* h, const uint8_t* d_grey, int nframes, const unsigned long long* d_flat, int flat_tp,
                                  rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
 hipError_t rcc_launch_pack_records(rcc_handle* h, int nframes, int frame_offset, double* d_table, hipStream_t s);

@@ -1,4 +1,4 @@
-// tag_detections_fill.h -- rcc_detection records -> the message the reference's consumer subscribes to.
+// tag_detections_fill.h -- rcc_detection records -> the messages the reference's consumer subscribes to.
 //
 // Kept apart from the ROS node (tag_detections_shim.cpp) so that it can be compiled and tested without
 // ROS: the message types are template parameters; the only thing assumed of them is the field names the
@@ -6,6 +6,8 @@
 // pixel_corners_y[0..3] (real_preprocessing/src/corner_detections.cpp:43-54) -- plus the upstream pose
 // field (never read by the reference).  Corner order bl, br, tr, tl (camera_pose.cpp:123-126).
 #pragma once
+#include <cstdint>
+#include <cstdlib>
 #include "rcc.h"
 
 template <class ArrayMsg, class DetMsg, class Header>
@@ -26,5 +28,32 @@ inline void rcc_fill_tag_detections(const rcc_detection* det, int n, const Heade
     d.pose.pose.pose.position.y = det[i].tvec[1];
     d.pose.pose.pose.position.z = det[i].tvec[2];
     out.detections.push_back(d);
+  }
+}
+
+// "tag_detections_image" (real_preprocessing/README.md:52,66: what the user watches in image_view to see that the tags
+// are found): the outline of every detection drawn into a copy of the input frame, bl->br->tr->tl->bl, the first edge
+// (bl->br) brighter so that the orientation shows.  Plain integer line rasteriser, clipped to the image; `channels`
+// 1 (mono8) or 3 (bgr8).
+inline void rcc_draw_detections(uint8_t* img, int width, int height, int step, int channels, const rcc_detection* det, int n)
+{
+  for (int i = 0; i < n; ++i) {
+    for (int e = 0; e < 4; ++e) {
+      int x0 = (int)det[i].corners[e][0], y0 = (int)det[i].corners[e][1];
+      const int x1 = (int)det[i].corners[(e + 1) & 3][0], y1 = (int)det[i].corners[(e + 1) & 3][1];
+      const int dx = std::abs(x1 - x0), sx = x0 < x1 ? 1 : -1, dy = -std::abs(y1 - y0), sy = y0 < y1 ? 1 : -1;
+      int err = dx + dy;
+      for (int guard = 0; guard < 4 * (width + height); ++guard) {
+        if (x0 >= 0 && x0 < width && y0 >= 0 && y0 < height) {
+          uint8_t* p = img + (size_t)y0 * step + (size_t)x0 * channels;
+          if (channels == 3) { p[0] = 0; p[1] = e == 0 ? 255 : 160; p[2] = e == 0 ? 0 : 255; }   // BGR: green first edge, orange others
+          else p[0] = e == 0 ? 255 : 0;
+        }
+        if (x0 == x1 && y0 == y1) break;
+        const int e2 = 2 * err;
+        if (e2 >= dy) { err += dy; x0 += sx; }
+        if (e2 <= dx) { err += dx; y0 += sy; }
+      }
+    }
   }
 }

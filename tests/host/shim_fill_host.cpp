@@ -39,3 +39,9 @@ extern "C" int shimfill_roundtrip(const rcc_detection* det, int n, unsigned seq,
   }
   return (int)msg.detections.size();
 }
+
+// the overlay of "tag_detections_image" (real_preprocessing/README.md:52,66)
+extern "C" void shimfill_draw(unsigned char* img, int width, int height, int step, int channels, const rcc_detection* det, int n)
+{
+  rcc_draw_detections(img, width, height, step, channels, det, n);
+}

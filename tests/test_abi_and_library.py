@@ -50,6 +50,20 @@ def test_library_exports_every_declared_symbol(built):
     assert declared == set(api.EXPORTED_SYMBOLS), declared ^ set(api.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(built, name), "librcc_hip.so does not export %s" % name
+    # the drop-in header carries no tap, timer or experiment; those live in rcc_debug.h
+    assert not [n for n in declared if n.startswith(("rcc_debug_", "rcc_time_"))]
+    dbg = open(os.path.join(ROOT, "include", "rcc_debug.h")).read()
+    product, experiments = dbg.split("#ifdef RCC_EXPERIMENTS")
+    ddecl = set(re.findall(r"\b(rcc_[a-z0-9_]+)\s*\(", product))
+    assert ddecl == set(api.DEBUG_EXPORTED_SYMBOLS), ddecl ^ set(api.DEBUG_EXPORTED_SYMBOLS)
+    for name in ddecl:
+        assert hasattr(built, name), "librcc_hip.so does not export %s" % name
+    # experiment entry points are NOT in the product library, and it reads no environment variable
+    for name in set(re.findall(r"\b(rcc_[a-z0-9_]+)\s*\(", experiments)):
+        assert not hasattr(built, name), "%s belongs to the -DRCC_EXPERIMENTS build only" % name
+    blob = open(api.library_path(), "rb").read()
+    for var in (b"RCC_DENSE_MEMONLY", b"RCC_DENSE_NSEG", b"RCC_DENSE_FCHUNK", b"RCC_RUNS_NSEG", b"RCC_INGEST_FPB", b"RCC_PNP_SOLVER"):
+        assert var not in blob, "the product library still knows the environment variable %s" % var.decode()
 
 
 def test_dist_library_exports_every_declared_symbol(built):

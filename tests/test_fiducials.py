@@ -280,3 +280,61 @@ def test_tag_pose_mfma_form_matches_vector_form_and_oracle(oracle, reference_mod
             assert a.id == b.id
             assert np.abs(a.rvec - np.array(list(b.rvec))).max() <= 1e-4 and np.abs(a.tvec - np.array(list(b.tvec))).max() <= 1e-4
         k0 += k
+
+
+@pytest.mark.gpu
+def test_shim_configuration_end_to_end_through_the_reference_consumer():
+    """The optional ROS node (host/tag_detections_shim.cpp) configured as it configures itself -- RAW image
+    (undistort = 0), square fiducials, plumb-bob D -- and then the reference's own chain replayed on its output:
+    message fields (host/tag_detections_fill.h) -> the consumer's int() casts and detections_N.yaml
+    (corner_detections.cpp:46-56, 27-37) -> camera_pose_node's solve: object points +-size/2, the int corners, K and D
+    (camera_pose.cpp:152-163, through rcc_solve_pnp_batch).  The poses must be the rendered ones up to the pixel
+    truncation the reference applies itself -- which they are not if the corners were those of an undistorted image
+    (distortion applied twice) or if `size` did not span the four corners."""
+    import ctypes as C, os, yaml
+    import torch
+    import tests.test_tagmap_yaml as TY
+    cfg, fam = _cfg(api.default_config, B=2)
+    cfg.undistort = 0                                       # as the node sets it: corners of the raw image
+    (hx, hy), centres, ids, sp = _scene(cfg)
+    det = api.Detector(cfg)
+    n = 2
+    poses = np.concatenate([synth.sample_poses(1, cfg, seed=500 + f, z_range=(0.9, 1.4), max_tilt_deg=35, half_extent_m=(hx, hy)) for f in range(n)])
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    dets, _ = det.detect(frames, n)
+    assert len(dets) == n * GX * GY
+    TY.test_ros_shim_message_filling()                      # (re)builds the message-filling library
+    Ls = C.CDLL(os.path.join(TY.ROOT, "tests", "host", "libshimfill_host.so"))
+    Lt = C.CDLL(TY.SO)
+    Lt.rcc_yaml_detections.restype = C.c_size_t
+    Lt.rcc_yaml_detections.argtypes = [C.c_char_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    K = np.array(list(cfg.K)); D = np.array(list(cfg.D))
+    worst_t = worst_R = 0.0
+    for f in range(n):
+        mine = dets[dets.frame == f]
+        m = len(mine)
+        recs = (abi.rcc_detection * m).from_buffer_copy(np.ascontiguousarray(mine).tobytes())
+        out = np.zeros(13 * m); asint = np.zeros(8 * m, np.int32)
+        assert Ls.shimfill_roundtrip(recs, m, f, out.ctypes.data_as(C.c_void_p), asint.ctypes.data_as(C.c_void_p)) == m
+        ids_m = np.ascontiguousarray(out.reshape(m, 13)[:, 0].astype(np.int32))
+        sizes = np.ascontiguousarray(out.reshape(m, 13)[:, 1])
+        corners = np.ascontiguousarray(np.stack([asint.reshape(m, 2, 4)[:, 0, :], asint.reshape(m, 2, 4)[:, 1, :]], -1).astype(np.int32))   # m x 4 x (x, y)
+        buf = C.create_string_buffer(1 << 16)
+        Lt.rcc_yaml_detections(buf, len(buf), m, ids_m.ctypes.data_as(C.c_void_p), sizes.ctypes.data_as(C.c_void_p), corners.ctypes.data_as(C.c_void_p))
+        doc = yaml.safe_load(buf.value.decode())            # what camera_pose.cpp:134-143 reads back
+        objs, imgs, tag_ids = [], [], []
+        for d in doc["detections"]:
+            s = float(d["size"][0]) / 2.0
+            objs.append(np.array([[-s, -s, 0], [s, -s, 0], [s, s, 0], [-s, s, 0]]))          # camera_pose.cpp:158-161
+            imgs.append(np.array([d["corners"][k] for k in range(4)], float))                # bl, br, tr, tl (:152-155)
+            tag_ids.append(int(d["targetID"]))
+        rv, tv, rms, st, it = det.solve_pnp(objs, imgs, K, D, abi.RCC_DIST_PLUMB_BOB)         # solvePnP(obj, img, K, D, ...) (:163)
+        assert (st == 0).all() and sorted(tag_ids) == list(ids)
+        R = synth.rodrigues(poses[f][:3])
+        for q, i in enumerate(tag_ids):
+            c = centres[list(ids).index(i)]
+            worst_t = max(worst_t, np.abs(tv[q] - (R @ c + poses[f][3:])).max())
+            worst_R = max(worst_R, np.abs(synth.rodrigues(rv[q]) - R).max())
+    det.close()
+    assert worst_t < 0.04 and worst_R < 0.2, (worst_t, worst_R)      # 4-point poses from int-truncated corners of ~60 px tags

@@ -1,0 +1,127 @@
+"""Build-time guard of the band kernel's COUNTED wait (csrc/dense_band_body.h).
+
+The threshold + corner band kernels synchronise a tile row with `s_waitcnt vmcnt(2 * BAND_DEPTH - 1)` + `s_barrier`
+instead of draining the vector-memory queue: that is correct only while every wave issues, on EVERY path through one
+loop iteration, its LDS-DMA of the tile row BAND_DEPTH ahead FIRST and then at least one store -- so that the DMA that is
+waited for always has at least 2 * BAND_DEPTH - 1 younger operations.  hipcc has broken such an assumption once (it merged
+three padding stores of the prologue into one: a race at 3840x2160), and nothing in the C++ says what
+the compiler may do to the loop.  So this test compiles the kernel to ISA (device code only, no GPU needed) and checks,
+for every instantiation, in the instruction stream itself:
+  * each of the three unrolled iterations starts with exactly `s_waitcnt vmcnt(2 * BAND_DEPTH - 1) lgkmcnt(0)`, `s_barrier`;
+  * the first vector-memory operation after the barrier is the LDS-DMA (`buffer_load_dwordx4 ... lds`), optionally
+    followed by ONE conditional second DMA (the ninth chunk of a wide band) whose branch rejoins immediately, and then
+    the flush store -- all before any other branch, i.e. unconditionally;
+  * no `s_waitcnt vmcnt(0)` was inserted into the loop, except behind an atomic that returns a value or a spill reload
+    (the candidate list's slot reservation: rare path) -- a drain elsewhere would not break correctness but would
+    serialise the pipeline;
+  * the prologue waits outright (`vmcnt(0)`) before the first barrier, and the kernel drains before it ends.
+It fails if someone -- or a new hipcc -- changes the number or the order of vector-memory operations per iteration."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "robot_camera_calibration_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def listing():
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    out = os.path.join(CSRC, "k_dense_band.isa.s")
+    deps = [os.path.join(CSRC, f) for f in ("k_dense_band.hip", "dense_band_body.h", "dense_rows.h", "rcc_internal.h")]
+    if not os.path.exists(out) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(out):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                               "-o", out, os.path.join(CSRC, "k_dense_band.hip")], stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
+
+
+def _kernels(lines):
+    """{mangled name: [instruction / label lines]} for the k_dense_band* kernels"""
+    out, name = {}, None
+    for l in lines:
+        m = re.match(r"^(_Z\d+k_dense_band\S*):", l)
+        if m:
+            name = m.group(1); out[name] = []; continue
+        if name is None:
+            continue
+        t = l.strip()
+        if t.startswith(".Lfunc_end"):
+            name = None; continue
+        if not t or t.startswith(";") or (t.startswith(".") and not re.match(r"^\.LBB\d+_\d+:", t)):
+            continue
+        out[name].append(t)
+    return out
+
+
+def _is_dma(t): return t.startswith("buffer_load_dwordx4") and t.rstrip().endswith("lds")
+def _is_store(t): return t.startswith(("buffer_store", "global_store", "flat_store"))
+def _is_vmem(t): return t.startswith(("buffer_", "global_", "flat_", "scratch_"))
+def _is_branch(t): return t.startswith(("s_cbranch", "s_branch"))
+def _is_label(t): return re.match(r"^\.LBB\d+_\d+:", t) is not None
+
+
+def test_counted_wait_invariant_holds_in_the_compiled_band_kernels(listing):
+    depth = int(re.search(r"#define\s+BAND_DEPTH\s+(\d+)", open(os.path.join(CSRC, "dense_band_body.h")).read()).group(1))
+    want_wait = "s_waitcnt vmcnt(%d) lgkmcnt(0)" % (2 * depth - 1)
+    kernels = _kernels(listing)
+    # every instantiation the launcher can pick: stage / compact forms, one-band / wide-band rings, fused and sweep-only
+    assert len(kernels) >= 8, sorted(kernels)
+    for name, ins in kernels.items():
+        bars = [i for i, t in enumerate(ins) if t.startswith("s_barrier")]
+        assert len(bars) == 3, "%s: %d barriers (the loop is unrolled by three)" % (name, len(bars))
+        for b in bars:
+            assert ins[b - 1].replace("  ", " ") == want_wait, "%s: barrier preceded by '%s', not '%s'" % (name, ins[b - 1], want_wait)
+            # ---- the unconditional head of the iteration: DMA [, conditional second DMA that rejoins at once], store
+            ev = []
+            j = b + 1
+            while j < len(ins) and len(ev) < 6:
+                t = ins[j]
+                if _is_dma(t): ev.append("DMA")
+                elif _is_store(t): ev.append("ST")
+                elif _is_vmem(t): ev.append("VMEM:" + t.split()[0])
+                elif _is_branch(t): ev.append("BR")
+                elif _is_label(t): ev.append("LABEL")
+                elif t.startswith("s_waitcnt") and "vmcnt" in t: ev.append("WAIT:" + t)
+                if ev and ev[-1] == "ST":
+                    break
+                j += 1
+            assert ev in (["DMA", "ST"], ["DMA", "BR", "DMA", "LABEL", "ST"]), "%s: iteration head is %s" % (name, ev)
+        # ---- no drain inside the loop
+        first, last = bars[0], bars[-1]
+        for i, t in enumerate(ins):
+            if not (t.startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", t)):
+                continue
+            if i < first:
+                continue                                                     # prologue: waits outright, by design
+            # the candidate path (rare: a wave that found corners) reserves list slots with a returning atomic, and in the
+            # register-capped compact kernel reloads a few spilled values there: both wait for their own result
+            behind_atomic = any(("atomic" in u) or u.startswith("scratch_load") for u in ins[max(0, i - 24):i])
+            before_end = any(u.startswith("s_endpgm") for u in ins[i:i + 8])
+            assert behind_atomic or before_end, "%s: '%s' inside the loop (instruction %d; barriers at %s)" % (name, t, i, bars)
+        # ---- prologue and epilogue drains exist
+        assert any(t.startswith("s_waitcnt") and "vmcnt(0)" in t for t in ins[:first]), "%s: the prologue no longer waits outright" % name
+        ends = [i for i, t in enumerate(ins) if t.startswith("s_endpgm")]
+        assert ends and any(any(u.startswith("s_waitcnt") and "vmcnt(0)" in u for u in ins[max(0, e - 8):e]) for e in ends), \
+            "%s: no drain of the in-flight DMA before the kernel ends" % name
+
+
+def test_guard_catches_a_broken_iteration(listing):
+    """the checker itself: drop the flush store of one iteration from a copy of the listing and it must object"""
+    kernels = _kernels(listing)
+    name, ins = sorted(kernels.items())[0]
+    b = [i for i, t in enumerate(ins) if t.startswith("s_barrier")][1]
+    j = next(i for i in range(b + 1, len(ins)) if _is_store(ins[i]))
+    broken = ins[:j] + ins[j + 1:]
+    ev = []
+    for t in broken[b + 1:]:
+        if _is_dma(t): ev.append("DMA")
+        elif _is_store(t): ev.append("ST")
+        elif _is_branch(t): ev.append("BR")
+        elif _is_label(t): ev.append("LABEL")
+        if ev and ev[-1] == "ST" or len(ev) >= 6:
+            break
+    assert ev not in (["DMA", "ST"], ["DMA", "BR", "DMA", "LABEL", "ST"])

@@ -138,7 +138,9 @@ def test_ros_shim_message_filling():
     one id, one size, four corners in the order bl, br, tr, tl, and the consumer's int() cast of them."""
     import ctypes as C, subprocess
     so = os.path.join(ROOT, "tests", "host", "libshimfill_host.so")
-    if not os.path.exists(so):
+    src = os.path.join(ROOT, "tests", "host", "shim_fill_host.cpp")
+    hdr = os.path.join(ROOT, "robot_camera_calibration_amd", "host", "tag_detections_fill.h")
+    if not os.path.exists(so) or max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(so):
         subprocess.check_call(["g++", "-O2", "-std=c++14", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-o", so,
                                os.path.join(ROOT, "tests", "host", "shim_fill_host.cpp")])
     L = C.CDLL(so)
@@ -162,3 +164,32 @@ def test_ros_shim_message_filling():
             assert asint[8 * i + k] == int(det[i].corners[k][0]) and asint[8 * i + 4 + k] == int(det[i].corners[k][1])
         assert list(o[10:13]) == [det[i].tvec[0], det[i].tvec[1], det[i].tvec[2]]
     assert L.shimfill_roundtrip(det, 0, 1, out.ctypes.data_as(C.c_void_p), asint.ctypes.data_as(C.c_void_p)) == 0   # empty array: consumer skips it
+
+
+def test_ros_shim_detection_image_overlay():
+    """N3: the overlay the node publishes on tag_detections_image (README.md:52,66): every detection's outline
+    bl -> br -> tr -> tl -> bl drawn into a copy of the frame, clipped at the image border, bgr8 and mono8"""
+    import ctypes as C
+    test_ros_shim_message_filling()                      # (re)builds tests/host/libshimfill_host.so
+    L = C.CDLL(os.path.join(ROOT, "tests", "host", "libshimfill_host.so"))
+    from robot_camera_calibration_amd import abi
+    det = (abi.rcc_detection * 2)()
+    quad = [(20.7, 60.2), (70.1, 58.9), (72.4, 12.3), (18.2, 10.8)]       # bl, br, tr, tl
+    for k, (x, y) in enumerate(quad):
+        det[0].corners[k][0], det[0].corners[k][1] = x, y
+        det[1].corners[k][0], det[1].corners[k][1] = x + 60.0, y - 30.0    # partly outside an 100 x 80 image
+    for ch in (3, 1):
+        img = np.full((80, 100 * ch + 4), 7, np.uint8)                     # 4 bytes of row padding
+        L.shimfill_draw(img.ctypes.data_as(C.c_void_p), 100, 80, img.shape[1], ch, det, 2)
+        px = img[:, :100 * ch].reshape(80, 100, ch)
+        changed = (px != 7).any(-1)
+        assert (img[:, 100 * ch:] == 7).all()                              # nothing written outside the rows
+        for (x, y) in quad:
+            assert changed[int(y), int(x)]                                 # the corners themselves are on the outline
+        assert changed[59, 45] or changed[60, 45] or changed[58, 45]       # a point of the bottom edge
+        assert not changed[35, 45]                                         # the inside stays untouched
+        assert 100 < changed.sum() < 600
+        if ch == 3:
+            row = [r for r in (58, 59, 60) if changed[r, 45]][0]
+            assert (px[row, 45] == [0, 255, 0]).all()                     # first edge (bl -> br) in its own colour
+            assert (px[int(quad[3][1]), int(quad[3][0])] == [0, 160, 255]).all()
