@@ -557,3 +557,54 @@ def test_rccl_allgather_records_world1(torch_cuda):
     torch.cuda.synchronize()
     assert torch.equal(out, tab)
     L.rcc_dist_destroy(h)
+
+
+@pytest.mark.parametrize("kind", ["board_bgr_plumb_bob", "board_mono_no_distortion", "tags_bgr_plumb_bob", "board_mono_fisheye"])
+def test_synthetic_camera_matches_oracle_renderer(torch_cuda, oracle, kind):
+    """N4: the generator that feeds every other test and the bench (csrc/k_synth.hip, standing where rviz_simulator's
+    missing camera.h was meant to be: rviz_simulator/include/rviz_simulator/target.h:40) against the oracle's renderer
+    (oracle/orc_synth.c) on the same poses.  Plumb-bob and undistorted cameras use only + - x / on fp64 (no fused
+    multiply-add on either side): bit-exact.  The fisheye camera goes through tan() and sqrt(), where the device and
+    host math libraries may round differently: a supersample that sits exactly on a class boundary can then change
+    class, i.e. one pixel moves by up to (white - black) / s^2 levels; the test states the bound and reports the count."""
+    torch = torch_cuda
+    w, h, n = (320, 240, 3)
+    mono = "mono" in kind
+    cfg = _make(w=w, h=h, pixfmt=abi.RCC_PIX_MONO8 if mono else abi.RCC_PIX_BGR8, B=n)
+    sp = abi.default_synth_params(seed=4242)
+    fam = None
+    if "no_distortion" in kind:
+        abi.set_distortion(cfg, abi.RCC_DIST_NONE, ())
+    if "fisheye" in kind:
+        abi.set_distortion(cfg, abi.RCC_DIST_FISHEYE, abi.FISHEYE_DEFAULT)
+    if kind.startswith("tags"):
+        fam = abi.load_family()
+        abi.set_fiducial_target(cfg, fam, tag_size=0.10, max_targets=6)
+        (hx, hy), _, _ = synth.fiducial_grid_layout(3, 2, cfg.tag_size)
+        sp.fid_grid_x, sp.fid_grid_y, sp.fid_gap_permille = 3, 2, 500
+        poses = synth.sample_poses(n, cfg, seed=77, z_range=(0.8, 1.4), max_tilt_deg=40, half_extent_m=(hx, hy))
+    else:
+        poses = synth.sample_poses(n, cfg, seed=77, z_range=(2.0, 3.0))
+    det = api.Detector(cfg)
+    frames = torch.zeros((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    det.synth_render(sp, poses, frames, first_index=5)
+    got = frames.cpu().numpy()
+    det.close()
+    ocfg = api.clone_config(cfg)
+    if fam is not None:
+        ocfg.family_codes = fam.ctypes.data          # the oracle reads the caller's table (the product copied it at create)
+    ch = 1 if mono else 3
+    ndiff, worst = 0, 0
+    for f in range(n):
+        ref = oracle.synth_render(ocfg, sp, poses[f], 5 + f)
+        g = got[f].reshape(h, cfg.stride_bytes)[:, :w * ch].reshape(ref.shape)
+        d = np.abs(g.astype(np.int16) - ref.astype(np.int16))
+        ndiff += int((d != 0).sum()); worst = max(worst, int(d.max()))
+        assert len(np.unique(ref)) > 20                # a real picture, not a constant
+    if "fisheye" in kind:
+        bound = (sp.white - sp.black + 18) // (sp.supersample ** 2) + 1
+        print("fisheye renderer: %d of %d samples differ, max |diff| %d (bound %d)" % (ndiff, n * w * h * ch, worst, bound))
+        assert worst <= bound and ndiff <= n * w * h * ch // 2000
+    else:
+        assert ndiff == 0, "%d pixels differ (max %d)" % (ndiff, worst)
