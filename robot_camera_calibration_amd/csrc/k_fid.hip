@@ -14,7 +14,10 @@
 // corners, 16-pixel edge probes for the pairs that pass, a handful of decodes -- VALU-bound once ~1000 frames are
 // resident, never bandwidth-bound; frames are the parallel axis.  DESIGN.md section 5 has the history.
 #include "rcc_internal.h"
-#define RCC_PNP_NOINLINE 1
+// The solver routines of pnp_core.h are inlined (no RCC_PNP_NOINLINE): round 1 kept them out of line after a suspected
+// hipcc -O3 miscompile that round 2 could not reproduce -- the fully inlined -O3 build passes every pose parity test
+// (the one recorded failure was the test's own: the Rodrigues round trip is not unique beyond |r| = pi) and is faster
+// (24 456 tag poses 0.45 -> 0.31 ms, board pose 0.27 -> 0.25 ms; profiles/r02_e_pnp_inline.txt).
 #include "pnp_core.h"
 
 #define FID_MAXN RCC_MAX_KEPT_FIDUCIAL

@@ -14,9 +14,10 @@
 // The result record layout is the C ABI's rcc_detection (what corner_detections.cpp:46-56 reads,
 // plus the pose).
 #include "rcc_internal.h"
-// hipcc -O3 (ROCm 7.2) miscompiles the fully inlined solver: wrong poses, and -O2 never terminates
-// (measured on MI355X; -O1, the host build and this out-of-line form all match the oracle to 1e-15).
-#define RCC_PNP_NOINLINE 1
+// The solver routines of pnp_core.h are inlined (no RCC_PNP_NOINLINE): round 1 kept them out of line after a suspected
+// hipcc -O3 miscompile that round 2 could not reproduce -- the fully inlined -O3 build passes every pose parity test
+// (the one recorded failure was the test's own: the Rodrigues round trip is not unique beyond |r| = pi) and is faster
+// (24 456 tag poses 0.45 -> 0.31 ms, board pose 0.27 -> 0.25 ms; profiles/r02_e_pnp_inline.txt).
 #include "pnp_core.h"
 #include "grid_frame.h"
 

@@ -19,7 +19,10 @@
 //
 // Measured against the vector form: profiles/r02_*_pnp_mfma.txt, DESIGN.md section 5.
 #include "rcc_internal.h"
-#define RCC_PNP_NOINLINE 1
+// The solver routines of pnp_core.h are inlined (no RCC_PNP_NOINLINE): round 1 kept them out of line after a suspected
+// hipcc -O3 miscompile that round 2 could not reproduce -- the fully inlined -O3 build passes every pose parity test
+// (the one recorded failure was the test's own: the Rodrigues round trip is not unique beyond |r| = pi) and is faster
+// (24 456 tag poses 0.45 -> 0.31 ms, board pose 0.27 -> 0.25 ms; profiles/r02_e_pnp_inline.txt).
 #include "pnp_core.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));

@@ -25,9 +25,9 @@
 #endif
 #endif
 
-// Device builds keep the big routines out of line: hipcc -O3 (ROCm 7.2) miscompiles the fully
-// inlined solver (wrong poses at 256 VGPRs + scratch; -O1 and the host build are right), and
-// separate frames also cut the spilling.  See DESIGN.md section 5.
+// RCC_PNP_NOINLINE (off by default) keeps the big routines out of line in device builds: an A/B knob.  Inlined is the
+// measured-faster form and matches the oracle in every parity test (the miscompile suspected in
+// round 1 was not reproducible).
 #if defined(__HIPCC__) && defined(RCC_PNP_NOINLINE)
 #define RCC_NI __attribute__((noinline))
 #else
