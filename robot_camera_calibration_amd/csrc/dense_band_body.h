@@ -7,7 +7,9 @@
 #define BAND_WAVES 8
 #define BAND_W RCC_BAND_W
 #ifndef BAND_DEPTH
-#define BAND_DEPTH 2          // tile rows of DMA in flight ahead of the front stage
+#define BAND_DEPTH 1          // tile rows of DMA in flight ahead of the front stage.  1 since round 2: with the leaner row
+                              // pipeline the pass measures 0.93 -> 0.86 ms (compact form, 1024 x 1080p) against depth 2, and the
+                              // stage form's ring (4 slots, 48 KB with its output stage) then fits three workgroups per CU
 #endif
 #define BAND_RING (BAND_DEPTH + 3)   // + the row being read by the front, and the two behind it the back stage reads
 #define BAND_OPITCH 2048
@@ -49,8 +51,11 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
 {
   constexpr int BAND_SLOT = NCH * 1024;
   constexpr bool THR = (MODE == 2);
-  uint8_t* const ring = lds;                               // BAND_RING * BAND_SLOT
-  uint8_t* const obuf = lds + BAND_RING * BAND_SLOT;        // THR ? 2 * RCC_THR_PITCH : 2 * BAND_OBUF
+  // output stage first (at an LDS address that is a multiple of 16 KiB: its two halves are then told apart by ONE
+  // address bit, and "the other half" is an xor on a per-lane offset), the ring behind it (1 KiB aligned for the DMA)
+  constexpr int OB_HALF = THR ? RCC_THR_PITCH : BAND_OBUF;
+  uint8_t* const obuf = lds;                                // 2 * OB_HALF
+  uint8_t* const ring = lds + 2 * OB_HALF;                  // BAND_RING * BAND_SLOT
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int band = job % nbands;
@@ -94,24 +99,28 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
   const unsigned fl_rd = (unsigned)(dk * BAND_OPITCH + 256 * wv + 16 * di);
   const int fl_voff = fl_ok ? dk * w + fl_col : BAND_INVALID;
 
-  // tile row tt -> ring; rows clamped to the image (as load_row of the strip kernel)
+  // tile row tt -> ring; rows clamped to the image (as load_row of the strip kernel).  The image height is a multiple of 4
+  // (rcc_dense_band_supported), so a tile row lies wholly inside the image or wholly outside: inside, lane (dk, di) reads
+  // row 4 tt + dk -- a per-lane constant plus a scalar row offset; outside, every lane reads the clamped row (0 or h - 1).
+  const int v_in = (int)__umul24((unsigned)dk, (unsigned)w) + dma_col, v_edge = dma_col;
   auto issue_dma = [&](int tt, int slot) {
-    const int row = __builtin_amdgcn_readfirstlane(4 * tt);
-    const int rr = min(max(row + dk, 0), h - 1);
-    dma_1k(rs_g, ring_lds + (unsigned)(slot * BAND_SLOT + wv * 1024), (int)__umul24((unsigned)rr, (unsigned)w) + dma_col, 0);
-    if (need_c8) dma_1k(rs_g, ring_lds + (unsigned)(slot * BAND_SLOT + 8 * 1024), (int)__umul24((unsigned)rr, (unsigned)w) + dma_col + 2048, 0);
+    const bool inside = (tt >= 0) && (tt < th);                                       // scalar
+    const int soff = __builtin_amdgcn_readfirstlane(inside ? 4 * tt * w : (tt < 0 ? 0 : (h - 1) * w));
+    const int voff = inside ? v_in : v_edge;
+    dma_1k(rs_g, ring_lds + (unsigned)(slot * BAND_SLOT + wv * 1024), voff, soff);
+    if (need_c8) dma_1k(rs_g, ring_lds + (unsigned)(slot * BAND_SLOT + 8 * 1024), voff + 2048, soff);
   };
   // the staged output of tile row tt (written one iteration ago) -> global, whole lines: four image rows of 256
   // bytes per wave, or (THR) the band's 512-byte map row by waves 0 and 1.  Every wave issues the store (dropped
   // through an out-of-range offset where it has nothing to write): the counted wait relies on it.
-  auto flush = [&](int tt, int buf) {
+  auto flush = [&](int tt, unsigned ob_fl) {
     const bool ok = (tt >= t0) && (tt < t1);                   // scalar
     if (THR) {
-      const unsigned q = *reinterpret_cast<const unsigned*>(obuf + buf * RCC_THR_PITCH + ((256 * wv + 4 * lane) & (RCC_THR_PITCH - 1)));
+      const unsigned q = *reinterpret_cast<const unsigned*>(obuf + ob_fl);
       __builtin_amdgcn_raw_buffer_store_b32(q, rs_b, (ok && wv < 2) ? 256 * wv + 4 * lane : BAND_INVALID,
                                             __builtin_amdgcn_readfirstlane(ok ? tt * RCC_THR_PITCH : 0), 0);
     } else {
-      const u32x4 q = *reinterpret_cast<const u32x4*>(obuf + buf * BAND_OBUF + fl_rd);
+      const u32x4 q = *reinterpret_cast<const u32x4*>(obuf + ob_fl);
       __builtin_amdgcn_raw_buffer_store_b128(q, rs_b, ok ? fl_voff : BAND_INVALID, __builtin_amdgcn_readfirstlane(ok ? 4 * tt * w : 0), 0);
     }
   };
@@ -124,13 +133,13 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
     T.g3 = *reinterpret_cast<const unsigned*>(p + 768);
     return T;
   };
-  auto stage_thr = [&](int buf, int level) {     // THR: one byte per lane = its tile of this tile row
-    if (lane_out) obuf[buf * RCC_THR_PITCH + wr_off] = (uint8_t)level;
+  auto stage_thr = [&](unsigned ob_wr, int level) {     // THR: one byte per lane = its tile of this tile row
+    if (lane_out) obuf[ob_wr] = (uint8_t)level;
   };
-  auto stage_out = [&](int buf, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+  auto stage_out = [&](unsigned ob_wr, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
     if (THR) return;
     if (lane_out) {
-      uint8_t* p = obuf + buf * BAND_OBUF + wr_off;
+      uint8_t* p = obuf + ob_wr;
       *reinterpret_cast<unsigned*>(p) = v0;
       *reinterpret_cast<unsigned*>(p + BAND_OPITCH) = v1;
       *reinterpret_cast<unsigned*>(p + 2 * BAND_OPITCH) = v2;
@@ -150,6 +159,10 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
 #endif
   int thrB = 0, flatB = 1;
   int sf = 0;                                                  // ring slot of tile row t (scalar)
+  // staging half of iteration t is t & 1, the half being flushed the other one: two per-lane offsets, each flipped by an
+  // xor per iteration (offsets within a half stay below OB_HALF, the stage sits on a 2 * OB_HALF boundary)
+  unsigned ob_wr = wr_off + (unsigned)(((t0 - 2) & 1) * OB_HALF);
+  unsigned ob_fl = (THR ? (unsigned)((256 * wv + 4 * lane) & (RCC_THR_PITCH - 1)) : fl_rd) + (unsigned)(((t0 - 3) & 1) * OB_HALF);
 
   // One iteration t (FRONT on tile row t, BACK on tile row tau = t-2: see the strip kernel for the skip rule)
   auto do_tile = [&](const int t, const TStat& ha, const TStat& hb, TStat& hn,
@@ -166,8 +179,10 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
     const int sd = (sf + BAND_DEPTH >= BAND_RING) ? sf + BAND_DEPTH - BAND_RING : sf + BAND_DEPTH;
     const int sb2 = (sf >= 2) ? sf - 2 : sf + BAND_RING - 2;
     issue_dma(t + BAND_DEPTH, sd);       // the slot held tile row t-3, last read in iteration t-1
-    flush(t - 3, (t - 1) & 1);
-    const int ob = t & 1;
+    flush(t - 3, ob_fl);
+    const unsigned ob = ob_wr;
+    ob_fl ^= (unsigned)OB_HALF;
+    ob_wr ^= (unsigned)OB_HALF;
     if (MODE == 1) {
       const Tile4 C = read_tile(sf), B = read_tile(sb2);
       stage_out(ob, B.g0 ^ C.g0, B.g1 ^ C.g1, B.g2 ^ C.g2, B.g3 ^ C.g3);

@@ -26,6 +26,18 @@ __device__ __forceinline__ u16x2 as_u(unsigned v) { return __builtin_bit_cast(u1
 __device__ __forceinline__ unsigned bits(i16x2 v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ unsigned bits(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
+// lane l + lane l-1's / lane l+1's value in ONE instruction (VOP2 with a DPP source; lanes without a source add 0): the
+// compiler folds a DPP move into a two-operand add but not into v_add3
+__device__ __forceinline__ int add_from_left0(int from, int addend) { return addend + from_left0(from); }
+__device__ __forceinline__ int add_from_right0(int from, int addend) { return addend + from_right0(from); }
+// dot2 with a zero accumulator in its VOP3P form (the builtin becomes v_mov 0 + v_dot2c)
+__device__ __forceinline__ int dot2z(i16x2 a, i16x2 b)
+{
+  int d;
+  asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 struct HSum { int xx0, xy0, yy0, xx2, xy2, yy2; };   // raw 5-px row sums at pixel 0 and pixel 2 of the lane
 struct SobelRow { i16x2 dh01, dh23, sh01, sh23; };     // horizontal Sobel partials of one row (pixel pairs 0-1, 2-3)
 struct Tile4 { unsigned g0, g1, g2, g3; };             // grey dwords of the four rows of a tile row
@@ -54,9 +66,13 @@ __device__ __forceinline__ TStat tile_stats(const Tile4& C)
     tmx = __builtin_elementwise_max(tmx, __builtin_elementwise_max(n0, n1));
   }
   const int tmin = min((int)tmn.x, (int)tmn.y), tmax = max((int)tmx.x, (int)tmx.y);
+  // neighbours by DPP with zero fill for the lanes that have none: harmless for a maximum of non-negative values, so
+  // the minimum is taken as the maximum of 255 - v.  Each max folds its DPP source (v_max_i32_dpp): 2 + 4 instructions
+  // instead of 4 copies + 4 DPP moves + min3 / max3.
+  const int nmin = 255 - tmin;
   TStat hn;
-  hn.hmin = min(tmin, min(from_left(tmin, tmin), from_right(tmin, tmin)));
-  hn.hmax = max(tmax, max(from_left(tmax, tmax), from_right(tmax, tmax)));
+  hn.hmax = max(max(tmax, from_left0(tmax)), from_right0(tmax));
+  hn.hmin = 255 - max(max(nmin, from_left0(nmin)), from_right0(nmin));
   return hn;
 }
 
@@ -86,6 +102,7 @@ struct Thr4 {
 struct RowPipe {
   HSum hprev, qa, qb;          // qa: pair closed at k=0, qb: pair closed at k=2
   LRow Ra, Rb;                 // lattice rows y-4, y-2
+  i16x2 two_splat;             // (2, 2), opaque to the optimiser: see row()
   // job constants
   int x0, w, h, t0, t1, margin, hthresh, cap, f, lane;
   bool lane_out;
@@ -93,6 +110,9 @@ struct RowPipe {
 
   __device__ __forceinline__ void reset()
   {
+    unsigned t2 = 0x00020002u;
+    asm volatile("" : "+v"(t2));
+    two_splat = __builtin_bit_cast(i16x2, t2);
     hprev = HSum{ 0, 0, 0, 0, 0, 0 }; qa = hprev; qb = hprev;
     Ra = LRow{ INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN }; Rb = Ra;
   }
@@ -119,7 +139,9 @@ struct RowPipe {
     const u16x2 mm = as_u(__builtin_amdgcn_perm(0u, G, 0x0C020C01u));    // [p1,p2]
     const u16x2 lh = as_u(__builtin_amdgcn_perm(GL, G, 0x0C000C07u));    // [p-1,p0]
     const u16x2 rh = as_u(__builtin_amdgcn_perm(GR, G, 0x0C040C03u));    // [p3,p4]
-    const i16x2 two = (i16x2)(2);
+    // 2 * x + y as ONE v_pk_mad_i16: the multiplier comes from a register the optimiser cannot see through (a literal 2
+    // is strength-reduced to a shift and the fused form is lost)
+    const i16x2 two = two_splat;
     n.dh01 = as_i(bits(mm)) - as_i(bits(lh));                            // I[x+1]-I[x-1] for x = p0,p1
     n.dh23 = as_i(bits(rh)) - as_i(bits(mm));
     n.sh01 = as_i(bits(n0)) * two + as_i(bits(lh)) + as_i(bits(mm));     // I[x-1]+2I[x]+I[x+1]
@@ -130,22 +152,20 @@ struct RowPipe {
     const i16x2 gy01 = (n.sh01 - a.sh01) >> 3;
     const i16x2 gy23 = (n.sh23 - a.sh23) >> 3;
     // ---- stage C (row rho): products + horizontal 5-sums at pixels 0 and 2
-    const int d0xx = __builtin_amdgcn_sdot2(gx01, gx01, 0, false);
-    const int d0xy = __builtin_amdgcn_sdot2(gx01, gy01, 0, false);
-    const int d0yy = __builtin_amdgcn_sdot2(gy01, gy01, 0, false);
-    const int d1xx = __builtin_amdgcn_sdot2(gx23, gx23, 0, false);
-    const int d1xy = __builtin_amdgcn_sdot2(gx23, gy23, 0, false);
-    const int d1yy = __builtin_amdgcn_sdot2(gy23, gy23, 0, false);
+    //   sum at px 0 = left lane's (p2, p3) + own (p0, p1) + own p2;  sum at px 2 = own (p0 .. p3) + right lane's p0.
+    // Seven instructions per quantity: the single products ride in as dot2 accumulators, the neighbour terms as DPP
+    // sources of two-operand adds (ten with the builtin dot2 on a zero accumulator and three-operand adds).
     const int ax0 = gx01.x, ay0 = gy01.x, ax2 = gx23.x, ay2 = gy23.x;
     const int q0xx = __mul24(ax0, ax0), q0xy = __mul24(ax0, ay0), q0yy = __mul24(ay0, ay0);
     const int q2xx = __mul24(ax2, ax2), q2xy = __mul24(ax2, ay2), q2yy = __mul24(ay2, ay2);
+    const int d1xx = dot2z(gx23, gx23), d1xy = dot2z(gx23, gy23), d1yy = dot2z(gy23, gy23);
     HSum hc;
-    hc.xx0 = d0xx + q2xx + from_left0(d1xx);
-    hc.xy0 = d0xy + q2xy + from_left0(d1xy);
-    hc.yy0 = d0yy + q2yy + from_left0(d1yy);
-    hc.xx2 = d0xx + d1xx + from_right0(q0xx);
-    hc.xy2 = d0xy + d1xy + from_right0(q0xy);
-    hc.yy2 = d0yy + d1yy + from_right0(q0yy);
+    hc.xx0 = add_from_left0(d1xx, __builtin_amdgcn_sdot2(gx01, gx01, q2xx, false));
+    hc.xy0 = add_from_left0(d1xy, __builtin_amdgcn_sdot2(gx01, gy01, q2xy, false));
+    hc.yy0 = add_from_left0(d1yy, __builtin_amdgcn_sdot2(gy01, gy01, q2yy, false));
+    hc.xx2 = __builtin_amdgcn_sdot2(gx01, gx01, add_from_right0(q0xx, d1xx), false);
+    hc.xy2 = __builtin_amdgcn_sdot2(gx01, gy01, add_from_right0(q0xy, d1xy), false);
+    hc.yy2 = __builtin_amdgcn_sdot2(gy01, gy01, add_from_right0(q0yy, d1yy), false);
     // ---- stage D/E/F: vertical sums on the lattice, response, selection
     if ((k & 1) == 0) {
       // rho = r-1 is odd: close the pair (rho-1, rho) into qa (k = 0) or qb (k = 2)

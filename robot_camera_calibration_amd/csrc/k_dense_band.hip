@@ -50,10 +50,19 @@
   const int fr_ = (8 * grp_ + (((int)(blockIdx.x & 7u) - grp_) & 7)) * fchunk + r_ / jpf_; \
   if (fr_ >= nframes) return;                                                           \
   const int job = fr_ * jpf_ + r_ % jpf_
+// three workgroups per CU for the stage form too: 48 KB of LDS at BAND_DEPTH 1, and an 80-register cap (4 dwords spill, in
+// the candidate path); measured 1.07 -> 1.03 ms per 1024 x 1080p against two workgroups per CU at 89 registers
+#if BAND_DEPTH == 1
+#define STAGE_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))
+#define STAGE_WGS 3
+#else
+#define STAGE_ATTR
+#define STAGE_WGS 2
+#endif
 template <int MODE, int PRIO, int NCH, bool SPLIT = false>
-__global__ __launch_bounds__(512) void k_dense_band(BAND_ARGS)
+__global__ __launch_bounds__(512) STAGE_ATTR void k_dense_band(BAND_ARGS)
 {
-  __shared__ __attribute__((aligned(1024))) uint8_t lds[BandLds<MODE, NCH>::bytes];
+  __shared__ __attribute__((aligned(16384))) uint8_t lds[BandLds<MODE, NCH>::bytes];
   BAND_JOB;
   dense_band_body<MODE, PRIO, NCH, SPLIT>(BAND_PASS);
 }
@@ -63,7 +72,7 @@ __global__ __launch_bounds__(512) void k_dense_band(BAND_ARGS)
 template <int MODE, int PRIO, int NCH>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_dense_band_occ6(BAND_ARGS)
 {
-  __shared__ __attribute__((aligned(1024))) uint8_t lds[BandLds<MODE, NCH>::bytes];
+  __shared__ __attribute__((aligned(16384))) uint8_t lds[BandLds<MODE, NCH>::bytes];
   BAND_JOB;
   dense_band_body<MODE, PRIO, NCH>(BAND_PASS);
 }
@@ -129,7 +138,7 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
   // of every frame flat).  Rule: up to 6 segments of at least 32 tile rows (16 while the launch does not fill the slots);
   // among them the largest count whose last round is within 2 % of the fullest.
   static const int cus = [] { hipDeviceProp_t p; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&p, d) == hipSuccess) ? p.multiProcessorCount : 256; }();
-  const long long slots = (long long)cus * (thr ? 3 : 2), base = (long long)nbands * nframes;
+  const long long slots = (long long)cus * (thr ? 3 : STAGE_WGS), base = (long long)nbands * nframes;
   int nseg = 1;
   {
     double best = 1e30;

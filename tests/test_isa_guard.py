@@ -64,6 +64,39 @@ def _is_branch(t): return t.startswith(("s_cbranch", "s_branch"))
 def _is_label(t): return re.match(r"^\.LBB\d+_\d+:", t) is not None
 
 
+def _head_events(ins, b):
+    """vector-memory operations every wave issues after the barrier at ins[b], in order, up to and including the first
+    UNCONDITIONAL store: 'DMA' / 'ST' / 'VMEM:<op>' outside any branch, 'cDMA' for an LDS-DMA inside a short forward skip
+    (the ninth chunk of a wide band).  A forward branch whose target label follows within 60 instructions opens a
+    conditional region that ends at that label (scalar address selection compiles to such diamonds); any other branch
+    ends the unconditional head."""
+    ev, skip_to, j = [], None, b + 1
+    while j < len(ins):
+        t = ins[j]
+        if skip_to is not None and t.startswith(skip_to + ":"):
+            skip_to = None
+        elif _is_branch(t):
+            target = t.split()[-1]
+            ahead = [k for k in range(j + 1, min(len(ins), j + 60)) if ins[k].startswith(target + ":")]
+            if skip_to is None and ahead:
+                skip_to = target
+            elif skip_to is None:
+                break                                   # a far / backward branch: the head is over
+        elif _is_vmem(t):
+            if skip_to is None:
+                ev.append("DMA" if _is_dma(t) else "ST" if _is_store(t) else "VMEM:" + t.split()[0])
+                if ev[-1] == "ST":
+                    break
+            elif _is_dma(t):
+                ev.append("cDMA")
+            else:
+                ev.append("cVMEM:" + t.split()[0])
+        elif t.startswith(("s_barrier", "s_endpgm")):
+            break
+        j += 1
+    return ev
+
+
 def test_counted_wait_invariant_holds_in_the_compiled_band_kernels(listing):
     depth = int(re.search(r"#define\s+BAND_DEPTH\s+(\d+)", open(os.path.join(CSRC, "dense_band_body.h")).read()).group(1))
     want_wait = "s_waitcnt vmcnt(%d) lgkmcnt(0)" % (2 * depth - 1)
@@ -76,20 +109,8 @@ def test_counted_wait_invariant_holds_in_the_compiled_band_kernels(listing):
         for b in bars:
             assert ins[b - 1].replace("  ", " ") == want_wait, "%s: barrier preceded by '%s', not '%s'" % (name, ins[b - 1], want_wait)
             # ---- the unconditional head of the iteration: DMA [, conditional second DMA that rejoins at once], store
-            ev = []
-            j = b + 1
-            while j < len(ins) and len(ev) < 6:
-                t = ins[j]
-                if _is_dma(t): ev.append("DMA")
-                elif _is_store(t): ev.append("ST")
-                elif _is_vmem(t): ev.append("VMEM:" + t.split()[0])
-                elif _is_branch(t): ev.append("BR")
-                elif _is_label(t): ev.append("LABEL")
-                elif t.startswith("s_waitcnt") and "vmcnt" in t: ev.append("WAIT:" + t)
-                if ev and ev[-1] == "ST":
-                    break
-                j += 1
-            assert ev in (["DMA", "ST"], ["DMA", "BR", "DMA", "LABEL", "ST"]), "%s: iteration head is %s" % (name, ev)
+            ev = _head_events(ins, b)
+            assert ev[:1] == ["DMA"] and "ST" in ev and all(e in ("DMA", "ST", "cDMA") for e in ev), "%s: iteration head is %s" % (name, ev)
         # ---- no drain inside the loop
         first, last = bars[0], bars[-1]
         for i, t in enumerate(ins):
@@ -116,12 +137,10 @@ def test_guard_catches_a_broken_iteration(listing):
     b = [i for i, t in enumerate(ins) if t.startswith("s_barrier")][1]
     j = next(i for i in range(b + 1, len(ins)) if _is_store(ins[i]))
     broken = ins[:j] + ins[j + 1:]
-    ev = []
-    for t in broken[b + 1:]:
-        if _is_dma(t): ev.append("DMA")
-        elif _is_store(t): ev.append("ST")
-        elif _is_branch(t): ev.append("BR")
-        elif _is_label(t): ev.append("LABEL")
-        if ev and ev[-1] == "ST" or len(ev) >= 6:
-            break
-    assert ev not in (["DMA", "ST"], ["DMA", "BR", "DMA", "LABEL", "ST"])
+    ev = _head_events(broken, b)
+    assert not (ev[:1] == ["DMA"] and "ST" in ev and all(e in ("DMA", "ST", "cDMA") for e in ev)), ev
+    # ... and a store that only some waves issue (moved behind a short forward branch) does not count either
+    k = next(i for i in range(b + 1, len(ins)) if _is_dma(ins[i]))
+    cond = ins[:j] + ["s_cbranch_scc1 .LBB999_1", ins[j], ".LBB999_1:"] + ins[j + 1:]
+    ev = _head_events(cond, b)
+    assert not (ev[:1] == ["DMA"] and "ST" in ev and all(e in ("DMA", "ST", "cDMA") for e in ev)) or ev.index("ST") > 1, ev
