@@ -41,7 +41,9 @@ int rcc_set_pnp_variant(rcc_handle* h, int variant);
 
 /* ---- timers (HIP events on the launch stream) ------------------------------------------------------------------------ */
 /* stage times of the last synchronous rcc_detect_batch / stage call, ms: [0] ingest, [1] threshold+corner,
- * [2] list + sub-pixel (+ grid when not fused), [3] pose (+ grid when fused), [4] d2h.  Returns the slots written. */
+ * [2] list + sub-pixel (+ grid when not fused), [3] pose (+ grid when fused), [4] d2h (-1 where not recorded: after
+ * rcc_detect_batch_collect only [1] is set -- the threshold + corner launch as it ran inside that step).  Returns the
+ * slots written. */
 int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n);
 /* name(s) of the kernel(s) the last threshold + corner launch used, as rocprofv3's kernel trace prints them */
 const char* rcc_last_dense_kernel(const rcc_handle* h);

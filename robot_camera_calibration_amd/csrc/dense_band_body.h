@@ -4,6 +4,7 @@
 #pragma once
 #include "dense_rows.h"
 
+#define RCC_BAND_ST_AUX 2     // nt: the binary image is written once and read by nothing of this kernel
 #define BAND_WAVES 8
 #define BAND_W RCC_BAND_W
 #ifndef BAND_DEPTH
@@ -24,7 +25,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma_1k(i32x4 rsrc, unsigned lds_addr, int voff, int soff)
 {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+  // nt: the grey image is read once by this pass and is far larger than the caches -- as a non-temporal stream it does not
+  // push the pass's own output lines out (measured with the nt stores below: stage form 1.03 -> 0.99 ms per 1024 x 1080p)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
                : "memory");
@@ -121,7 +124,7 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
                                             __builtin_amdgcn_readfirstlane(ok ? tt * RCC_THR_PITCH : 0), 0);
     } else {
       const u32x4 q = *reinterpret_cast<const u32x4*>(obuf + ob_fl);
-      __builtin_amdgcn_raw_buffer_store_b128(q, rs_b, ok ? fl_voff : BAND_INVALID, __builtin_amdgcn_readfirstlane(ok ? 4 * tt * w : 0), 0);
+      __builtin_amdgcn_raw_buffer_store_b128(q, rs_b, ok ? fl_voff : BAND_INVALID, __builtin_amdgcn_readfirstlane(ok ? 4 * tt * w : 0), RCC_BAND_ST_AUX);
     }
   };
   auto read_tile = [&](int slot) -> Tile4 {

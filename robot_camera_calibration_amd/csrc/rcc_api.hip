@@ -124,6 +124,7 @@ void rcc_destroy(rcc_handle* h)
   if (h->h_det2) (void)hipHostFree(h->h_det2);
   if (h->h_ndet2) (void)hipHostFree(h->h_ndet2);
   for (auto& e : h->sub_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& p : h->sub_dense_ev) for (auto& e : p) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   for (auto& ps : h->pstream) if (ps) (void)hipStreamDestroy(ps);
@@ -196,6 +197,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
       hipHostMalloc((void**)&h->h_det2, B * (size_t)cfg->max_targets * sizeof(rcc_detection)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_ndet2, B * sizeof(int32_t)) != hipSuccess) { rcc_destroy(h); return RCC_ERR_NOMEM; }
   for (auto& e : h->sub_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
+  for (auto& p : h->sub_dense_ev) for (auto& e : p) if (hipEventCreate(&e) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   {
     // object points of the board: index = row*cols + col, x right, y up, z = 0, origin at the
     // centre -- the object-frame convention of camera_pose.cpp:158-161
@@ -569,7 +571,9 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   const int slots = h->cfg.max_targets;
   HIPCHK(h, rcc_launch_ingest(h, d_frames, nframes, h->d_grey, s));
   h->want_thr = h->keep_bin ? 0 : 1;
+  HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][0], s));
   HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
+  HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][1], s));
   h->want_thr = 0;
   int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, false);
   if (r != RCC_OK) return r;
@@ -608,6 +612,8 @@ int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet)
     }
   }
   if (ndet) *ndet = n;
+  // the one stage time the streaming form records: the threshold + corner launch as it ran INSIDE this step
+  (void)hipEventElapsedTime(&h->last_ms[1], h->sub_dense_ev[slot][0], h->sub_dense_ev[slot][1]);
   h->sub_nframes[slot] = 0;
   ++h->sub_tail;
   return RCC_OK;

@@ -91,6 +91,7 @@ struct rcc_handle {
   rcc_detection* h_det2;
   int32_t* h_ndet2;
   hipEvent_t sub_ev[2];     // results of the submission in slot i are in pinned memory
+  hipEvent_t sub_dense_ev[2][2];   // around the threshold + corner launch of the submission in slot i (its in-step duration)
   int sub_nframes[2];       // frames of the submission in slot i (0: slot free)
   hipStream_t sub_stream[2];
   unsigned sub_head, sub_tail;   // submissions issued / collected
