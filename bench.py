@@ -34,8 +34,8 @@ PCIE_GBS = 63.0                # MI355X_MICROARCH.md: PCIe Gen5 x16 (spec)
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)     # the first ~5 steps after start-up run 2-10 % slower than the steady state
+    ap.add_argument("--warmup", type=int, default=5)     # (scratch/t_steps.py): defaults long enough to measure the latter
     ap.add_argument("--batch", type=int, default=1024, help="frames per rank per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -85,22 +85,28 @@ def run_steps(det, frames, B, gather, steps, sync_steps):
     has detect / submit / collect (tests/test_dist_gloo.py drives it with a stand-in on CPU ranks)."""
     found = 0
     run_steps.dense_ms = []          # in-step duration of the threshold + corner launch of every streamed step (HIP events)
+    # ranks that exchange device-packed tables keep the detector on the stream the collective is ordered with, and count
+    # the gathered records (a host synchronisation) only after the last step
+    kw = {"stream": gather.stream} if getattr(gather, "stream", None) is not None else {}
     if sync_steps:
-        for _ in range(steps):
-            dets, _ = det.detect(frames, B, want_corners=False)
-            found = gather.exchange(dets, 0)
+        for k in range(steps):
+            getattr(gather, "before_submit", lambda s: None)(0)
+            dets, _ = det.detect(frames, B, want_corners=False, **kw)
+            found = gather.exchange(dets, 0, k == steps - 1)
     else:
         # the streaming form of the same K steps (rcc_detect_batch_submit / _collect): batch k+1 is launched before
         # the host unpacks batch k, so the device does not idle during the unpack and the exchange of the records.
         # Every step's work -- all kernels, the device-to-host copy, the unpack, the all_gather -- is inside the region.
-        det.submit(frames, B)
+        slot_of_next = getattr(det, "_nsub", 0) & 1          # result slot (and record table) of the next submission
+        before = getattr(gather, "before_submit", lambda s: None)
+        before(slot_of_next); det.submit(frames, B, **kw); slot_of_next ^= 1
         for k in range(steps):
             if k + 1 < steps:
-                det.submit(frames, B)
+                before(slot_of_next); det.submit(frames, B, **kw); slot_of_next ^= 1
             dets, _ = det.collect()
             if hasattr(det, "last_timings"):
                 run_steps.dense_ms.append(det.last_timings()["dense"])
-            found = gather.exchange(dets, getattr(det, "last_slot", 0))
+            found = gather.exchange(dets, getattr(det, "last_slot", 0), k == steps - 1)
     return found
 
 
@@ -145,8 +151,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
+    if "WORLD_SIZE" in os.environ:          # launched by torchrun: the distributed path, whatever the world size (a world of
+        import torch.distributed as dist    # one still runs the RCCL calls: init, barrier, all_gather of the record tables)
         dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
         if dist.get_world_size() != a.gpus:
             sys.stderr.write("bench.py: RCCL world of %d ranks, --gpus %d\n" % (dist.get_world_size(), a.gpus))
@@ -193,7 +199,7 @@ def main():
 
     tpf = fid[0] * fid[1] if fid else 1
     gather = rdist.PoseGather(B, dev, world, dist, rank, targets_per_frame=tpf)
-    if world > 1:
+    if dist is not None:
         gather.attach(det, frame_offset=first)      # the detector packs the records on the device, every batch
 
     run_steps(det, frames, B, gather, a.warmup, True)

@@ -61,7 +61,8 @@ def pack(dets, nframes, targets_per_frame=1, frame_offset=0):
 
 
 class PoseGather:
-    """One all_gather of pose records per batch.  world == 1: no collective at all."""
+    """One all_gather of pose records per batch.  Without a process group (dist_module None: a single plain process) there
+    is no collective at all; with one, the collective runs whatever the world size."""
 
     def __init__(self, nframes, device, world, dist_module=None, rank=0, targets_per_frame=1):
         self.nframes, self.tpf = nframes, targets_per_frame
@@ -70,29 +71,61 @@ class PoseGather:
         on_gpu = getattr(device, "type", "cpu") == "cuda"
         # two send tables: the detector fills one per result slot (submit/collect keeps two batches in flight)
         self.tables = [torch.zeros((self.nslots, REC), dtype=torch.float64, device=device) for _ in range(2 if on_gpu else 1)]
-        self.recv = torch.zeros((world * self.nslots, REC), dtype=torch.float64, device=device) if world > 1 else None
+        self.recv = torch.zeros((world * self.nslots, REC), dtype=torch.float64, device=device) if dist_module is not None else None
         self.attached = False
         self.frame_offset = 0
+        # GPU ranks: the collective runs on a side stream so that the detector's stream never waits for it; `done[i]` marks
+        # the end of the last gather that read table i
+        self.side = torch.cuda.Stream(device) if on_gpu else None
+        self.done = [None, None]
 
     def attach(self, detector, frame_offset=0):
         """GPU ranks: let the detector pack its records into this gather's tables on the device"""
         detector.set_record_tables(self.tables[0], self.tables[-1], frame_offset)
         self.attached, self.frame_offset = True, frame_offset
 
-    def exchange(self, dets, slot=0):
+    def exchange(self, dets, slot=0, count=True):
         """One step's exchange, whatever the rank is made of: the device table of result slot `slot` when a detector
-        packs it (attach), else the host records; no collective at all in a world of one.  Returns the number of valid
-        records this rank sees."""
-        if self.world == 1 or self.dist is None:
+        packs it (attach), else the host records; no collective at all without a process group.  Returns the number of
+        valid records this rank sees -- or -1 with count=False on a GPU rank, which then only ENQUEUES the collective
+        (no host synchronisation: the caller keeps the detector on the stream the collective is ordered with,
+        `stream`, so nothing overwrites a table before it has been gathered)."""
+        if self.dist is None:
             return len(dets)
         if self.attached:
-            return self.run_table(self.tables[slot if slot < len(self.tables) else 0])
+            t = self.tables[slot if slot < len(self.tables) else 0]
+            i = slot if slot < len(self.tables) else 0
+            if self.side is None:
+                return self.run_table(t) if count else (self.dist.all_gather_into_tensor(self.recv, t), -1)[1]
+            # the table is complete (the caller has collected the batch), so the side stream has nothing to wait for
+            with torch.cuda.stream(self.side):
+                self.dist.all_gather_into_tensor(self.recv, t)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self.done[i] = ev
+                n = int((self.recv[:, 0] > 0.5).sum().item()) if count else -1
+            return n
         return self.run(dets, self.frame_offset)
+
+    def before_submit(self, slot):
+        """call before the detector is handed a batch whose records go to table `slot`: orders that batch (on the
+        detector's stream = torch's current stream) behind the gather that last read the table -- a device-side wait,
+        long satisfied by then"""
+        if self.side is not None and self.done[slot & 1] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.done[slot & 1])
+
+    @property
+    def stream(self):
+        """raw HIP stream handle the detector should launch on when its tables feed the collective (torch's current
+        stream: RCCL orders itself with it), or None"""
+        if self.attached and getattr(self.device, "type", "cpu") == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return None
 
     def run_table(self, table):
         """exchange a table that already sits on the device (filled by the detector); returns the number of valid
         records visible to this rank"""
-        if self.world == 1 or self.dist is None:
+        if self.dist is None:
             return int((table[:, 0] > 0.5).sum().item())
         self.dist.all_gather_into_tensor(self.recv, table)
         return int((self.recv[:, 0] > 0.5).sum().item())

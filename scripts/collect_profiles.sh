@@ -9,8 +9,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # the profiled run skips the host-input / batch-1 / CPU legs: they launch the same kernels on 1 .. 32 frames and would
 # drag the per-kernel averages of the summary away from the 1024-frame launches the roofline figures are about
-rocprofv3 --kernel-trace --stats -d $O/bench -o bench --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-extra-legs --no-cpu-baseline > $O/bench.json 2> $O/bench.err
-cd $R && python3 bench.py --steps 5 --warmup 1 > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err; cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/bench -o bench --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-extra-legs --no-cpu-baseline > $O/bench.json 2> $O/bench.err
+cd $R && python3 bench.py > $O/bench_unprofiled.json 2> $O/bench_unprofiled.err; cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $O/dense_$c -o p --output-format csv -- python3 $R/scripts/prof_dense.py 512 > $O/dense_$c.log 2>&1
   rocprofv3 --kernel-trace --pmc $c -d $O/ingest_$c -o p --output-format csv -- python3 $R/scripts/prof_ingest.py 256 > $O/ingest_$c.log 2>&1

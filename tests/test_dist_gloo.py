@@ -118,11 +118,11 @@ class _StandInDetector:
     def __init__(self, rank, nframes):
         self.rank, self.nframes, self._pending, self._nsub, self.calls = rank, nframes, [], 0, []
 
-    def detect(self, frames, n, want_corners=False):
+    def detect(self, frames, n, want_corners=False, stream=None):
         self.calls.append("detect")
         return _fake_dets(self.rank, n), None
 
-    def submit(self, frames, n):
+    def submit(self, frames, n, stream=None):
         assert len(self._pending) < 2, "more than two submissions outstanding"
         self.calls.append("submit")
         self._pending.append((n, self._nsub & 1)); self._nsub += 1
