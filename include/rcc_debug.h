@@ -28,6 +28,8 @@ extern "C" {
  * (k_dense_fast.hip), 3 = band sweep + corner kernel on the active rows (k_dense_runs.hip); -1 = automatic (1 where the
  * geometry allows it, else 2, else 0) */
 int rcc_set_dense_variant(rcc_handle* h, int variant);
+/* undistort + grey pass: 0 = gather (any geometry), 1 = LDS-staged tiles with the tabulated map, 2 = staged, map recomputed
+ * per block; -1 = automatic */
 int rcc_set_ingest_variant(rcc_handle* h, int variant);
 /* 1 (default): the marching dense kernels skip the corner stages on wave-rows whose tiles are all flat (exact); 0: never */
 int rcc_set_dense_skip(rcc_handle* h, int on);

@@ -167,7 +167,8 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
                                                    int64_t frame_bytes, int stride, int w, int h,
                                                    const rcc_cam& cam, uint8_t* __restrict__ grey,
                                                    int nframes, int fpb, int ntx, const int tile, const int bz, const int tid,
-                                                   uint8_t* lds, int* s_flag, const int half, const int nhalves)
+                                                   uint8_t* lds, int* s_flag, const int half, const int nhalves,
+                                                   const int2* __restrict__ map = nullptr, const int4* __restrict__ tilebox = nullptr)
 {
   const int tv = tile < 0 ? 0 : tile;
   const int by = tv / ntx, bx = tv - by * ntx;
@@ -179,6 +180,20 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
   const bool inside = (tile >= 0) && (y < h) && (x0 < w);          // w % 16 == 0: a quad is all in or all out
   int32_t X[4], Y[4];
   int mnx = INT32_MAX, mxx = INT32_MIN, mny = INT32_MAX, mxy = INT32_MIN;
+  if (map) {
+    // the Q5 map and the tile's source box are frame-invariant: tabulated once per handle by k_ingest_map (the same
+    // rcc_map_q5, so the same bits) -- 8 B per destination pixel per block of `fpb` frames instead of ~100 fp64
+    // instructions per pixel and a block-wide reduction (the pass is bound by instruction issue, not by HBM)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { X[j] = 0; Y[j] = 0; }
+    if (inside) {
+      const int4* mp = reinterpret_cast<const int4*>(map + (size_t)y * w + x0);
+      const int4 a = mp[0], b = mp[1];
+      X[0] = a.x; Y[0] = a.y; X[1] = a.z; Y[1] = a.w; X[2] = b.x; Y[2] = b.y; X[3] = b.z; Y[3] = b.w;
+    }
+    const int4 tb = tilebox[tv];
+    mnx = tb.x; mxx = tb.y; mny = tb.z; mxy = tb.w;
+  } else {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     X[j] = 0; Y[j] = 0;
@@ -200,6 +215,7 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
   mxx = max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1]));
   mny = min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2]));
   mxy = max(max(s_red[0][3], s_red[1][3]), max(s_red[2][3], s_red[3][3]));
+  }
   const int f0 = bz * fpb;
   const int f1 = min(f0 + fpb, nframes);
   // box in source pixels: columns [bxa, bxa + 16*gw), rows [by0, by0 + bh); taps need +1

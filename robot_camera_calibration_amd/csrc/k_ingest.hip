@@ -64,7 +64,8 @@ template <int NCH>
 __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict__ frames,
                                                        int64_t frame_bytes, int stride, int w, int h,
                                                        rcc_cam cam, uint8_t* __restrict__ grey,
-                                                       int nframes, int fpb, int ntx, int ntiles, int per_xcd)
+                                                       int nframes, int fpb, int ntx, int ntiles, int per_xcd,
+                                                       const int2* __restrict__ map, const int4* __restrict__ tilebox)
 {
   // XCD-aware tile order.  Workgroups go round-robin to the 8 XCDs (id % 8), each with its own L2; the source
   // boxes of neighbouring tiles overlap (about 14 source rows for 8 destination rows), so neighbours must share
@@ -77,7 +78,41 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   if (tile >= ntiles) return;                       // block-uniform
   __shared__ __attribute__((aligned(16))) uint8_t lds[ST_TILE_LDS];
   __shared__ int s_flag[2];
-  ingest_staged_body<NCH>(frames, frame_bytes, stride, w, h, cam, grey, nframes, fpb, ntx, tile, bz, threadIdx.x, lds, s_flag, 0, 1);
+  ingest_staged_body<NCH>(frames, frame_bytes, stride, w, h, cam, grey, nframes, fpb, ntx, tile, bz, threadIdx.x, lds, s_flag, 0, 1, map, tilebox);
+}
+
+// The frame-invariant part of the staged pass, once per handle: map[v * w + u] = Q5 source coordinates of destination
+// pixel (u, v) (rcc_map_q5, the arithmetic of the specification), and per 128 x 8 destination tile the bounding box of
+// the integer source coordinates (min x, max x, min y, max y) -- what ingest_staged_body otherwise recomputes per block.
+__global__ __launch_bounds__(256) void k_ingest_map(int w, int h, rcc_cam cam, int ntx, int2* __restrict__ map, int4* __restrict__ tilebox)
+{
+  __shared__ int s_red[4][4];
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int by = tile / ntx, bx = tile - by * ntx;
+  const int tx = tid & 31, ty = tid >> 5;
+  const int x0 = bx * ST_TW + tx * 4, y = by * ST_TH + ty;
+  const bool inside = (y < h) && (x0 < w);
+  int mnx = INT32_MAX, mxx = INT32_MIN, mny = INT32_MAX, mxy = INT32_MIN;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (inside) {
+      int32_t X, Y;
+      rcc_map_q5(cam, x0 + j, y, X, Y);
+      map[(size_t)y * w + x0 + j] = make_int2(X, Y);
+      mnx = min(mnx, X >> 5); mxx = max(mxx, X >> 5);
+      mny = min(mny, Y >> 5); mxy = max(mxy, Y >> 5);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    mnx = min(mnx, __shfl_xor(mnx, off, 64)); mxx = max(mxx, __shfl_xor(mxx, off, 64));
+    mny = min(mny, __shfl_xor(mny, off, 64)); mxy = max(mxy, __shfl_xor(mxy, off, 64));
+  }
+  if ((tid & 63) == 0) { s_red[tid >> 6][0] = mnx; s_red[tid >> 6][1] = mxx; s_red[tid >> 6][2] = mny; s_red[tid >> 6][3] = mxy; }
+  __syncthreads();
+  if (tid == 0)
+    tilebox[tile] = make_int4(min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0])), max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1])),
+                              min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2])), max(max(s_red[0][3], s_red[1][3]), max(s_red[2][3], s_red[3][3])));
 }
 
 // ---- no undistortion: pure streaming conversion -----------------------------------------------
@@ -163,11 +198,25 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
     const int tiles = ((w + ST_TW - 1) / ST_TW) * ((ht + ST_TH - 1) / ST_TH);
     while (fpb > 2 && (int64_t)tiles * ((nframes + fpb - 1) / fpb) < 4096) fpb >>= 1;
     const int ntx = (w + ST_TW - 1) / ST_TW, per_xcd = (tiles + 7) / 8, ngroups = (nframes + fpb - 1) / fpb;
+    if (!h->d_map && !h->map_failed) {
+      // first staged launch of this handle: tabulate the map (w * h * 8 B) and the tiles' source boxes
+      if (hipMalloc((void**)&h->d_map, (size_t)w * ht * sizeof(int2)) != hipSuccess || hipMalloc((void**)&h->d_tilebox, (size_t)tiles * sizeof(int4)) != hipSuccess) {
+        if (h->d_map) (void)hipFree(h->d_map);
+        h->d_map = nullptr; h->d_tilebox = nullptr; h->map_failed = 1;      // no room: the kernel recomputes the map itself
+        (void)hipGetLastError();
+      } else {
+        hipLaunchKernelGGL(k_ingest_map, dim3(tiles), dim3(256), 0, s, w, ht, cam, ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
+        (void)hipStreamSynchronize(s);      // once per handle: later launches may come on other streams
+      }
+    }
+    const int2* mp = h->ingest_table ? (const int2*)h->d_map : nullptr;
+    const int4* tb = h->ingest_table ? (const int4*)h->d_tilebox : nullptr;
+    if (!mp || !tb) { mp = nullptr; tb = nullptr; }
     dim3 grid(8 * per_xcd * ngroups);
     if (c.pixfmt == RCC_PIX_BGR8)
-      hipLaunchKernelGGL((k_ingest_staged<3>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb, ntx, tiles, per_xcd);
+      hipLaunchKernelGGL((k_ingest_staged<3>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb, ntx, tiles, per_xcd, mp, tb);
     else
-      hipLaunchKernelGGL((k_ingest_staged<1>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb, ntx, tiles, per_xcd);
+      hipLaunchKernelGGL((k_ingest_staged<1>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb, ntx, tiles, per_xcd, mp, tb);
     return hipGetLastError();
   }
   // frames per block: amortise the fp64 map; keep >= ~2048 blocks in flight

@@ -115,7 +115,7 @@ void rcc_destroy(rcc_handle* h)
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = { h->d_flat, h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
+  void* ptrs[] = { h->d_map, h->d_tilebox, h->d_flat, h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
                    h->d_kept, h->d_kept_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
                    h->d_board_obj, h->d_img_scratch, h->d_family, h->d_sp_tab };
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -155,6 +155,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->kept_cap = (cfg->target_kind == RCC_TARGET_FIDUCIAL) ? RCC_MAX_KEPT_FIDUCIAL : RCC_MAX_KEPT;
   h->pnp_solver = 1;
   h->pnp_use_mfma = cfg->pnp_use_mfma ? 1 : 0;
+  h->ingest_table = 1;
 #ifdef RCC_EXPERIMENTS
   if (const char* e = getenv("RCC_PNP_SOLVER")) h->pnp_solver = atoi(e);
 #endif
@@ -295,11 +296,15 @@ int rcc_set_pnp_mfma(rcc_handle* h, int on)
   h->pnp_use_mfma = on ? 1 : 0;
   return p;
 }
+// variant: 0 gather, 1 staged with the tabulated map (default where the geometry allows), 2 staged recomputing the map
+// per block; -1 automatic
 int rcc_set_ingest_variant(rcc_handle* h, int variant)
 {
   if (!h) return RCC_ERR_ARG;
   int p = h->ingest_variant;
-  h->ingest_variant = variant;
+  if (p == 1 && !h->ingest_table) p = 2;
+  h->ingest_table = (variant == 2) ? 0 : 1;
+  h->ingest_variant = (variant == 2) ? 1 : variant;
   return p;
 }
 
@@ -505,6 +510,7 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
       v.want_thr = h->keep_bin ? 0 : 1;
       hipStream_t cs = h->pstream[c & 1];
       hipError_t e = rcc_launch_ingest(&v, d_frames + (size_t)f0 * h->cfg.frame_bytes, f1 - f0, v.d_grey, cs);
+      h->d_map = v.d_map; h->d_tilebox = v.d_tilebox; h->map_failed = v.map_failed;     // tables built by the first launch belong to the handle
       if (e == hipSuccess) e = rcc_launch_dense(&v, v.d_grey, f1 - f0, v.d_bin, v.d_cand, v.d_cand_count, cs);
       if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s", hipGetErrorString(e)); return RCC_ERR_DEVICE; }
       int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, cs, false);

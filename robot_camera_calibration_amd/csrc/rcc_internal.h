@@ -65,6 +65,10 @@ struct rcc_handle {
   double* rec_table[2];     // rcc_set_record_tables: the caller's device tables, one per result slot (NULL: none)
   int rec_offset;           // global index of the batch's first frame in those tables
   const char* dense_kernel; // name(s) of the kernel(s) the last threshold + corner launch used, as rocprofv3 prints them
+  void* d_map;              // staged ingest: Q5 map of the handle's camera (w * h int2) and the tiles' source boxes (int4 each),
+  void* d_tilebox;          //   tabulated at the first staged launch (k_ingest_map)
+  int map_failed;           // the tables could not be allocated: the kernel recomputes the map per block
+  int ingest_table;         // 1 (default): use the tables; 0: recompute (A/B, tests)
   int fuse_grid_pnp;        // 1 (default): board validation / indexing and pose in one kernel (checkerboard, wave-per-board solver)
   int keep_bin;             // rcc_set_keep_binary: rcc_detect_batch writes the full binary image (default 0: the compact map)
   int want_thr;             // set by rcc_detect_batch: the dense pass may write d_thr instead of the full binary image
