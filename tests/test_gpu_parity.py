@@ -411,6 +411,15 @@ def test_submit_collect_stream(torch_cuda):
     assert rca.tobytes() == ca.tobytes() and rcb.tobytes() == cb.tobytes()
     d_again, _ = det.detect(fb, n)
     assert d_again.tobytes() == db.tobytes()
+    # all outstanding submissions share the handle's device buffers: a second stream while one is in flight is refused
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    det.submit(fa, n, stream=sa.cuda_stream)
+    with pytest.raises(api.RccError) as e:
+        det._chk(det._L.rcc_detect_batch_submit(det._h, api._ptr(fb), n, abi.RCC_MEM_DEVICE, None, C.c_void_p(sb.cuda_stream)), "submit on another stream")
+    assert e.value.status == abi.RCC_ERR_STATE
+    det.submit(fb, n, stream=sa.cuda_stream)               # the same stream is fine
+    r1, _ = det.collect(); r2, _ = det.collect()
+    assert r1.tobytes() == da.tobytes() and r2.tobytes() == db.tobytes()
     det.close()
 
 
