@@ -155,12 +155,15 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
   TStat H0 = { 255, 0 }, H1 = H0, H2 = H0;
   RowPipe P;
   P.reset();
-  P.x0 = x0; P.w = w; P.h = h; P.t0 = t0; P.t1 = t1; P.margin = margin; P.hthresh = hthresh; P.cap = cap; P.f = f; P.lane = lane;
-  P.lane_out = lane_out; P.cand = cand; P.cand_count = cand_count;
+  P.w = w; P.h = h; P.t0 = t0; P.t1 = t1; P.margin = margin; P.hthresh = hthresh; P.cap = cap; P.f = f;
+  P.cand = cand; P.cand_count = cand_count;
+  P.set_lane(x0, lane, lane_out);
 #ifdef RCC_BAND_TRACE
   long long tr_wait = 0, tr_act = 0; int tr_n = 0, tr_na = 0; const long long tr_0 = wall_clock64();
 #endif
-  int thrB = 0, flatB = 1;
+  int thrB = 0;
+  bool flatB = true;       // the flags below are lane masks (bool, not int): they live in scalar register pairs and the
+                           // skip vote is scalar arithmetic
   int sf = 0;                                                  // ring slot of tile row t (scalar)
   // staging half of iteration t is t & 1, the half being flushed the other one: two per-lane offsets, each flipped by an
   // xor per iteration (offsets within a half stay below OB_HALF, the stage sits on a 2 * OB_HALF boundary)
@@ -169,7 +172,7 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
 
   // One iteration t (FRONT on tile row t, BACK on tile row tau = t-2: see the strip kernel for the skip rule)
   auto do_tile = [&](const int t, const TStat& ha, const TStat& hb, TStat& hn,
-                     const int Fa, const int Fb, int& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
+                     const bool Fa, const bool Fb, bool& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
     // tile row t has landed in LDS for every wave (5 = the operations each wave has issued since its DMA of
     // tile row t), every wave has finished iteration t-1, and its LDS writes are visible
 #ifdef RCC_BAND_TRACE
@@ -195,8 +198,8 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
       const int dmin = min(ha.hmin, min(hb.hmin, hn.hmin)), dmax = max(ha.hmax, max(hb.hmax, hn.hmax));
       const int range = dmax - dmin;
       const int thrN = dmin + (range >> 1);
-      const int flatN = range < min_contrast;
-      Fn = allow_skip ? (((t - 1) < t0 - 1) ? 1 : flatN) : 0;   // warm-up rows: "don't care" (strip kernel)
+      const bool flatN = range < min_contrast;
+      Fn = allow_skip ? (((t - 1) < t0 - 1) ? true : flatN) : false;   // warm-up rows: "don't care" (strip kernel)
       // ---- BACK
       const int tau = t - 2;
       if (THR) stage_thr(ob, flatB ? 255 : thrB);            // tile row tau's level (thrB <= 254 when not flat)
@@ -204,7 +207,7 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
         // true flatness of tile row t-1, for the rows this segment owns (every row is written by exactly one segment)
         const int xr = t - 1;
         if ((xr >= t0 && xr < t1) || (xr == -1 && t0 == 0) || (xr == th && t1 == th)) {
-          const unsigned long long m = __ballot(flatN != 0);
+          const unsigned long long m = __ballot(flatN);
           if (lane == 0) fm[xr + 1] = m;
         }
         if (!THR && tau >= t0 - 2) {
@@ -224,9 +227,9 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
             const Thr4 thr(thrB, flatB);
             stage_out(ob, thr(B.g0), thr(B.g1), thr(B.g2), thr(B.g3));
           }
-          P.row(4 * tau + 0, 0, B.g0, sa, sb, sc, 0);
+          P.row(4 * tau + 0, 0, B.g0, sa, sb, sc, false);
           P.row(4 * tau + 1, 1, B.g1, sb, sc, sa, Fa);     // produces lattice row 4*tau-2, in tile row tau-1
-          P.row(4 * tau + 2, 2, B.g2, sc, sa, sb, 0);
+          P.row(4 * tau + 2, 2, B.g2, sc, sa, sb, false);
           P.row(4 * tau + 3, 3, B.g3, sa, sb, sc, Fb);     // produces lattice row 4*tau, in tile row tau
           if (PRIO) __builtin_amdgcn_s_setprio(0);
 #ifdef RCC_BAND_TRACE
@@ -251,7 +254,7 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
 #pragma unroll
   for (int d = 0; d < BAND_DEPTH; ++d) issue_dma(t + d, d);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  int F0 = allow_skip, F1 = allow_skip, F2 = allow_skip;
+  bool F0 = allow_skip != 0, F1 = F0, F2 = F0;
   const int tend = t1 + 2;                                // the back stage lags the front by two tile rows
   for (;;) {
     do_tile(t, H0, H1, H2, F0, F1, F2, S0, S1, S2);

@@ -26,6 +26,20 @@ __device__ __forceinline__ u16x2 as_u(unsigned v) { return __builtin_bit_cast(u1
 __device__ __forceinline__ unsigned bits(i16x2 v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ unsigned bits(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
+// the same two moves pinned to where they are written (the compiler hoists the builtin form out of a rarely taken
+// branch and pays for it on every row); s_nop 1: the wait states a DPP read needs after a vector write of its source
+__device__ __forceinline__ int from_left0_here(int v)
+{
+  int d;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(v));
+  return d;
+}
+__device__ __forceinline__ int from_right0_here(int v)
+{
+  int d;
+  asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(v));
+  return d;
+}
 // lane l + lane l-1's / lane l+1's value in ONE instruction (VOP2 with a DPP source; lanes without a source add 0): the
 // compiler folds a DPP move into a two-operand add but not into v_add3
 __device__ __forceinline__ int add_from_left0(int from, int addend) { return addend + from_left0(from); }
@@ -42,7 +56,8 @@ struct HSum { int xx0, xy0, yy0, xx2, xy2, yy2; };   // raw 5-px row sums at pix
 struct SobelRow { i16x2 dh01, dh23, sh01, sh23; };     // horizontal Sobel partials of one row (pixel pairs 0-1, 2-3)
 struct Tile4 { unsigned g0, g1, g2, g3; };             // grey dwords of the four rows of a tile row
 struct TStat { int hmin, hmax; };                      // horizontally dilated tile min / max
-struct LRow { int r0, r2, rL, rR; };                   // lattice row of responses: own px 0, px 2, left and right neighbour
+struct LRow { int r0, r2; };                           // lattice row of responses at the lane's px 0 and px 2 (the neighbour lanes'
+                                                       // values are fetched by DPP only where a row is searched for maxima)
 
 // "don't care" values that cost no instruction (the compiler may leave anything in the register)
 __device__ __forceinline__ void dontcare(int& v) { asm volatile("" : "=v"(v)); }
@@ -85,8 +100,8 @@ __device__ __forceinline__ TStat tile_stats(const Tile4& C)
 // 31 of either source as 0x00 / 0xFF) puts the four results back in pixel order.  6 instructions per dword with the
 // flat select (the carry-free byte compare it replaces took 9).
 struct Thr4 {
-  unsigned k; int flat;
-  __device__ __forceinline__ Thr4(int thr, int flat_) : flat(flat_) { k = __umul24((unsigned)(0x7FFF - thr), 0x10001u); }
+  unsigned k; bool flat;
+  __device__ __forceinline__ Thr4(int thr, bool flat_) : flat(flat_) { k = __umul24((unsigned)(0x7FFF - thr), 0x10001u); }
   __device__ __forceinline__ unsigned operator()(unsigned x) const
   {
     const unsigned e = (x & 0x00FF00FFu) + k;                               // [p0, p2]
@@ -103,31 +118,41 @@ struct RowPipe {
   LRow Ra, Rb;                 // lattice rows y-4, y-2
   i16x2 two_splat;             // (2, 2), opaque to the optimiser: see row()
   // job constants
-  int x0, w, h, t0, t1, margin, hthresh, cap, f, lane;
-  bool lane_out;
+  // xlane0 = first pixel of lane 0 (wave-uniform; the lane's own column and index are re-derived where a candidate is
+  // written instead of living in two registers through the loop); ok0 / ok2: may this lane report a candidate at its
+  // px 0 / px 2 (useful lane, column inside the window's output range and the margin) -- loop-invariant lane masks
+  int xlane0, w, h, t0, t1, margin, hthresh, cap, f;
+  bool ok0, ok2;
   rcc_cand* cand; int32_t* cand_count;
 
+  // (after w and margin are set)  x0: the lane's first pixel; lane_out: useful lane whose pixels lie in the columns this window reports
+  __device__ __forceinline__ void set_lane(int x0, int lane, bool lane_out)
+  {
+    xlane0 = __builtin_amdgcn_readfirstlane(x0 - 4 * lane);
+    ok0 = lane_out && x0 >= margin && x0 < w - margin;
+    ok2 = lane_out && x0 + 2 >= margin && x0 + 2 < w - margin;
+  }
   __device__ __forceinline__ void reset()
   {
     unsigned t2 = 0x00020002u;
     asm volatile("" : "+v"(t2));
     two_splat = __builtin_bit_cast(i16x2, t2);
     hprev = HSum{ 0, 0, 0, 0, 0, 0 }; qa = hprev; qb = hprev;
-    Ra = LRow{ INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN }; Rb = Ra;
+    Ra = LRow{ INT32_MIN, INT32_MIN }; Rb = Ra;
   }
   // a skipped tile row: the two lattice rows not produced lie in flat tiles; the row sums now describe rows
   // that were not read, and everything they can still reach is a masked response, so their contents do not
   // matter (no copies at the control-flow join)
   __device__ __forceinline__ void skip()
   {
-    Ra.r0 = Ra.r2 = Ra.rL = Ra.rR = INT32_MIN; Rb = Ra;
+    Ra.r0 = Ra.r2 = INT32_MIN; Rb = Ra;
     dontcare(hprev); dontcare(qa); dontcare(qb);
   }
 
   // one image row: G = its grey dword; (a, b) = Sobel partials of rows r-2, r-1; n receives row r's.
   // rmask != 0: the lane's tile at the lattice row being produced is flat => its response cannot
   // reach hthresh (host-checked bound), so it is replaced by INT32_MIN
-  __device__ __forceinline__ void row(const int r, const int k, const unsigned G, const SobelRow& a, const SobelRow& b, SobelRow& n, const int rmask)
+  __device__ __forceinline__ void row(const int r, const int k, const unsigned G, const SobelRow& a, const SobelRow& b, SobelRow& n, const bool rmask)
   {
     // ---- stage A (row r): horizontal Sobel partials, natural-order pixel pairs
     // zero for the lanes without a neighbour: that only changes lane 0's pixel -1 and lane 63's pixel 4, which
@@ -179,23 +204,27 @@ struct RowPipe {
       LRow Rn;
       Rn.r0 = rmask ? INT32_MIN : __mul24(A0, C0) - __mul24(B0, B0) - (int)(__umul24(tr0, tr0) >> 4);
       Rn.r2 = rmask ? INT32_MIN : __mul24(A2, C2) - __mul24(B2, B2) - (int)(__umul24(tr2, tr2) >> 4);
-      Rn.rL = from_left0(Rn.r2);           // lanes 0 / 63 (halo, never selected) see 0 instead of a neighbour
-      Rn.rR = from_right0(Rn.r0);
       hprev = hc;
       // selection on lattice row yc = rho - 4 = r - 5 (rows Ra = yc-2, Rb = yc, Rn = yc+2)
       const int yc = r - 5;
       const bool rowok = (yc >= 4 * t0) && (yc < 4 * t1) && (yc >= margin) && (yc < h - margin);
       if (rowok && __any((Rb.r0 >= hthresh) || (Rb.r2 >= hthresh))) {
-        const int xa = x0, xb = x0 + 2;
-        bool is0 = lane_out && Rb.r0 >= hthresh && xa >= margin && xa < w - margin &&
-                   Rb.r0 > Ra.rL && Rb.r0 > Ra.r0 && Rb.r0 > Ra.r2 && Rb.r0 > Rb.rL &&
-                   Rb.r0 >= Rb.r2 && Rb.r0 >= Rn.rL && Rb.r0 >= Rn.r0 && Rb.r0 >= Rn.r2;
-        bool is2 = lane_out && Rb.r2 >= hthresh && xb >= margin && xb < w - margin &&
-                   Rb.r2 > Ra.r0 && Rb.r2 > Ra.r2 && Rb.r2 > Ra.rR && Rb.r2 > Rb.r0 &&
-                   Rb.r2 >= Rb.rR && Rb.r2 >= Rn.r0 && Rb.r2 >= Rn.r2 && Rb.r2 >= Rn.rR;
+        // the neighbour lanes' responses, here only (the branch is wave-uniform: every lane is live for the DPP moves);
+        // lanes 0 / 63 (halo, never selected) see 0 instead of a neighbour
+        const int RaL = from_left0_here(Ra.r2), RbL = from_left0_here(Rb.r2), RnL = from_left0_here(Rn.r2);
+        const int RaR = from_right0_here(Ra.r0), RbR = from_right0_here(Rb.r0), RnR = from_right0_here(Rn.r0);
+        bool is0 = ok0 && Rb.r0 >= hthresh &&
+                   Rb.r0 > RaL && Rb.r0 > Ra.r0 && Rb.r0 > Ra.r2 && Rb.r0 > RbL &&
+                   Rb.r0 >= Rb.r2 && Rb.r0 >= RnL && Rb.r0 >= Rn.r0 && Rb.r0 >= Rn.r2;
+        bool is2 = ok2 && Rb.r2 >= hthresh &&
+                   Rb.r2 > Ra.r0 && Rb.r2 > Ra.r2 && Rb.r2 > RaR && Rb.r2 > Rb.r0 &&
+                   Rb.r2 >= RbR && Rb.r2 >= Rn.r0 && Rb.r2 >= Rn.r2 && Rb.r2 >= RnR;
         const unsigned long long m0 = __ballot(is0), m2 = __ballot(is2);
         const int n0c = __popcll(m0), n2c = __popcll(m2);
         if (n0c + n2c) {
+          int lane;
+          asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+          const int xa = xlane0 + 4 * lane, xb = xa + 2;
           int basei = 0;
           if (lane == 0) basei = atomicAdd(&cand_count[f], n0c + n2c);
           basei = __shfl(basei, 0);

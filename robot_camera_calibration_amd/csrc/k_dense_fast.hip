@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
   TStat H0 = { 255, 0 }, H1 = H0, H2 = H0;
   RowPipe P;
   P.reset();
-  P.x0 = x0; P.w = w; P.h = h; P.t0 = t0; P.t1 = t1; P.margin = margin; P.hthresh = hthresh; P.cap = cap; P.f = f; P.lane = lane;
-  P.lane_out = lane_out; P.cand = cand; P.cand_count = cand_count;
+  P.w = w; P.h = h; P.t0 = t0; P.t1 = t1; P.margin = margin; P.hthresh = hthresh; P.cap = cap; P.f = f;
+  P.cand = cand; P.cand_count = cand_count;
+  P.set_lane(x0, lane, lane_out);
 
   // addressing: buffer descriptors of the frame's grey / binary image + per-lane byte offset (VGPR, constant)
   // + row offset (SGPR): no vector arithmetic per access (a per-lane 64-bit multiply-add per access would cost
@@ -81,10 +82,11 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
   //     ago), one iteration early (Bn -> Bc) so that their latency is covered too.
   //   Fa / Fb / Fn = flatness of tile rows t-3 / t-2 / t-1 (Fn is set here); thrB / flatB = threshold
   //   level and true flatness of tile row t-2 (carried from the previous iteration).
-  int thrB = 0, flatB = 1;
+  int thrB = 0;
+  bool flatB = true;
   Tile4 Bc = { 0, 0, 0, 0 }, Bn = Bc;
   auto do_tile = [&](const int t, const Tile4& C, Tile4& N2, const TStat& ha, const TStat& hb, TStat& hn,
-                     const int Fa, const int Fb, int& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
+                     const bool Fa, const bool Fb, bool& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
     N2.g0 = load_row(4 * t + 8); N2.g1 = load_row(4 * t + 9); N2.g2 = load_row(4 * t + 10); N2.g3 = load_row(4 * t + 11);
     Bn.g0 = load_row(4 * t - 4); Bn.g1 = load_row(4 * t - 3); Bn.g2 = load_row(4 * t - 2); Bn.g3 = load_row(4 * t - 1);   // rows of tau+1
     if (MODE == 1) {
@@ -103,11 +105,11 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
     const int dmin = min(ha.hmin, min(hb.hmin, hn.hmin)), dmax = max(ha.hmax, max(hb.hmax, hn.hmax));
     const int range = dmax - dmin;
     const int thrN = dmin + (range >> 1);
-    const int flatN = range < min_contrast;
+    const bool flatN = range < min_contrast;
     // warm-up: tile rows below t0-1 produce no lattice row this job needs (the first needed one is
     // 4*t0-2, in tile row t0-1, whose statistics rest on t0-2..t0, all read), so their flag is "don't
     // care" = 1: back(t0-2) then runs iff tile row t0-1 is not flat, back(t0-1) iff t0-1 or t0 is not.
-    Fn = allow_skip ? (((t - 1) < t0 - 1) ? 1 : flatN) : 0;
+    Fn = allow_skip ? (((t - 1) < t0 - 1) ? true : flatN) : false;
     // ---- BACK
     const int tau = t - 2;
     if (tau >= t0 - 2) {
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
           store_row(4 * tau + 2, thr(Bc.g2));
           store_row(4 * tau + 3, thr(Bc.g3));
         }
-        P.row(4 * tau + 0, 0, Bc.g0, sa, sb, sc, 0);
+        P.row(4 * tau + 0, 0, Bc.g0, sa, sb, sc, false);
         P.row(4 * tau + 1, 1, Bc.g1, sb, sc, sa, Fa);     // produces lattice row 4*tau-2, in tile row tau-1
-        P.row(4 * tau + 2, 2, Bc.g2, sc, sa, sb, 0);
+        P.row(4 * tau + 2, 2, Bc.g2, sc, sa, sb, false);
         P.row(4 * tau + 3, 3, Bc.g3, sa, sb, sc, Fb);     // produces lattice row 4*tau, in tile row tau
       } else {
         if (out_row) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
   int t = t0 - 2;
   T0.g0 = load_row(4 * t); T0.g1 = load_row(4 * t + 1); T0.g2 = load_row(4 * t + 2); T0.g3 = load_row(4 * t + 3);
   T1.g0 = load_row(4 * t + 4); T1.g1 = load_row(4 * t + 5); T1.g2 = load_row(4 * t + 6); T1.g3 = load_row(4 * t + 7);
-  int F0 = allow_skip, F1 = allow_skip, F2 = allow_skip;
+  bool F0 = allow_skip != 0, F1 = F0, F2 = F0;
   const int tend = t1 + 2;                                // the back stage lags the front by two tile rows
   for (;;) {
     do_tile(t, T0, T2, H0, H1, H2, F0, F1, F2, S0, S1, S2);

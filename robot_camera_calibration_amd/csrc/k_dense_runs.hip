@@ -73,8 +73,9 @@ __global__ __launch_bounds__(64) void k_dense_runs(const uint8_t* __restrict__ g
   SobelRow S0 = { 0, 0, 0, 0 }, S1 = S0, S2 = S0;
   RowPipe P;
   P.reset();
-  P.x0 = x0; P.w = w; P.h = h; P.t0 = t0; P.t1 = t1; P.margin = margin; P.hthresh = hthresh; P.cap = cap; P.f = f; P.lane = lane;
-  P.lane_out = lane_out; P.cand = cand; P.cand_count = cand_count;
+  P.w = w; P.h = h; P.t0 = t0; P.t1 = t1; P.margin = margin; P.hthresh = hthresh; P.cap = cap; P.f = f;
+  P.cand = cand; P.cand_count = cand_count;
+  P.set_lane(x0, lane, lane_out);
 
   int L = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(AR));      // lane index of the row being computed
   AR &= AR - 1ull;
@@ -93,11 +94,11 @@ __global__ __launch_bounds__(64) void k_dense_runs(const uint8_t* __restrict__ g
     // masks of tile rows tau - 1 (lane L - 1) and tau (lane L)
     const unsigned alo = (unsigned)__builtin_amdgcn_readlane((int)flo, L - 1), ahi = (unsigned)__builtin_amdgcn_readlane((int)fhi, L - 1);
     const unsigned blo = (unsigned)__builtin_amdgcn_readlane((int)flo, L), bhi = (unsigned)__builtin_amdgcn_readlane((int)fhi, L);
-    const int Fa = (int)((((lane < 32) ? alo : ahi) >> (lane & 31)) & 1u);
-    const int Fb = (int)((((lane < 32) ? blo : bhi) >> (lane & 31)) & 1u);
-    P.row(4 * tau + 0, 0, Bc.g0, sa, sb, sc, 0);
+    const bool Fa = ((((lane < 32) ? alo : ahi) >> (lane & 31)) & 1u) != 0;
+    const bool Fb = ((((lane < 32) ? blo : bhi) >> (lane & 31)) & 1u) != 0;
+    P.row(4 * tau + 0, 0, Bc.g0, sa, sb, sc, false);
     P.row(4 * tau + 1, 1, Bc.g1, sb, sc, sa, Fa);     // produces lattice row 4*tau-2, in tile row tau-1
-    P.row(4 * tau + 2, 2, Bc.g2, sc, sa, sb, 0);
+    P.row(4 * tau + 2, 2, Bc.g2, sc, sa, sb, false);
     P.row(4 * tau + 3, 3, Bc.g3, sa, sb, sc, Fb);     // produces lattice row 4*tau, in tile row tau
     if (!more) return false;
     if (Ln != L + 1) {                                 // rows in between are not visited: state is "don't care"
