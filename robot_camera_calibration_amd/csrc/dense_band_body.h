@@ -72,7 +72,6 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
   const int x0 = X0 + wv * STRIP_USE - 8 + 4 * lane;           // first pixel of this lane
   const int xl = min(max(x0, 0), w - 4);                       // clamped column (as the strip kernel)
   const bool lane_out = (lane >= 2) && (lane <= 62) && (x0 >= X0) && (x0 < X1);
-  const bool lane_core = (lane >= 2) && (lane <= 62);
   const bool wave_on = (X0 + wv * STRIP_USE) < X1;             // wave-uniform: does this window hold band pixels?
   const uint8_t* gf = grey + (size_t)f * w * h;
   // output: the frame's binary image, or (THR) this band's slice of the frame's compact threshold map
@@ -162,8 +161,11 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
   long long tr_wait = 0, tr_act = 0; int tr_n = 0, tr_na = 0; const long long tr_0 = wall_clock64();
 #endif
   int thrB = 0;
-  bool flatB = true;       // the flags below are lane masks (bool, not int): they live in scalar register pairs and the
-                           // skip vote is scalar arithmetic
+  // the flat flags are kept as 64-bit ballots in scalar registers: the skip vote is scalar arithmetic on them, and a lane
+  // reads its own bit back as a select condition (inverse ballot), never as a 0 / 1 value in a vector register
+  typedef unsigned long long mask64;
+  mask64 flatB = ~0ull;
+  const mask64 core_lanes = 0x7FFFFFFFFFFFFFFCull;          // lanes 2..62 (lane_core)
   int sf = 0;                                                  // ring slot of tile row t (scalar)
   // staging half of iteration t is t & 1, the half being flushed the other one: two per-lane offsets, each flipped by an
   // xor per iteration (offsets within a half stay below OB_HALF, the stage sits on a 2 * OB_HALF boundary)
@@ -172,7 +174,7 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
 
   // One iteration t (FRONT on tile row t, BACK on tile row tau = t-2: see the strip kernel for the skip rule)
   auto do_tile = [&](const int t, const TStat& ha, const TStat& hb, TStat& hn,
-                     const bool Fa, const bool Fb, bool& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
+                     const mask64 Fa, const mask64 Fb, mask64& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
     // tile row t has landed in LDS for every wave (5 = the operations each wave has issued since its DMA of
     // tile row t), every wave has finished iteration t-1, and its LDS writes are visible
 #ifdef RCC_BAND_TRACE
@@ -198,39 +200,38 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
       const int dmin = min(ha.hmin, min(hb.hmin, hn.hmin)), dmax = max(ha.hmax, max(hb.hmax, hn.hmax));
       const int range = dmax - dmin;
       const int thrN = dmin + (range >> 1);
-      const bool flatN = range < min_contrast;
-      Fn = allow_skip ? (((t - 1) < t0 - 1) ? true : flatN) : false;   // warm-up rows: "don't care" (strip kernel)
+      const mask64 flatN = __builtin_amdgcn_ballot_w64(range < min_contrast);
+      Fn = allow_skip ? (((t - 1) < t0 - 1) ? ~0ull : flatN) : 0ull;   // warm-up rows: "don't care" (strip kernel)
       // ---- BACK
       const int tau = t - 2;
-      if (THR) stage_thr(ob, flatB ? 255 : thrB);            // tile row tau's level (thrB <= 254 when not flat)
+      if (THR) stage_thr(ob, __builtin_amdgcn_inverse_ballot_w64(flatB) ? 255 : thrB);            // tile row tau's level (thrB <= 254 when not flat)
       if (SPLIT) {
         // true flatness of tile row t-1, for the rows this segment owns (every row is written by exactly one segment)
         const int xr = t - 1;
         if ((xr >= t0 && xr < t1) || (xr == -1 && t0 == 0) || (xr == th && t1 == th)) {
-          const unsigned long long m = __ballot(flatN);
-          if (lane == 0) fm[xr + 1] = m;
+          if (lane == 0) fm[xr + 1] = flatN;
         }
         if (!THR && tau >= t0 - 2) {
-          if (__any(lane_out && !flatB)) {
+          if (wave_any(lane_out && !__builtin_amdgcn_inverse_ballot_w64(flatB))) {
             const Tile4 B = read_tile(sb2);
-            const Thr4 thr(thrB, flatB);
+            const Thr4 thr(thrB, __builtin_amdgcn_inverse_ballot_w64(flatB));
             stage_out(ob, thr(B.g0), thr(B.g1), thr(B.g2), thr(B.g3));
           } else {
             stage_out(ob, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
           }
         }
       } else if (tau >= t0 - 2) {
-        if (__any(lane_core && !(Fa && Fb && Fn))) {   // halo lanes do not vote: nothing they hold reaches an output
+        if ((core_lanes & ~(Fa & Fb & Fn)) != 0ull) {   // halo lanes do not vote: nothing they hold reaches an output
           if (PRIO) __builtin_amdgcn_s_setprio(2);          // the wave on the critical path of this iteration
           const Tile4 B = read_tile(sb2);
           if (!THR) {
-            const Thr4 thr(thrB, flatB);
+            const Thr4 thr(thrB, __builtin_amdgcn_inverse_ballot_w64(flatB));
             stage_out(ob, thr(B.g0), thr(B.g1), thr(B.g2), thr(B.g3));
           }
           P.row(4 * tau + 0, 0, B.g0, sa, sb, sc, false);
-          P.row(4 * tau + 1, 1, B.g1, sb, sc, sa, Fa);     // produces lattice row 4*tau-2, in tile row tau-1
+          P.row(4 * tau + 1, 1, B.g1, sb, sc, sa, __builtin_amdgcn_inverse_ballot_w64(Fa));     // produces lattice row 4*tau-2, in tile row tau-1
           P.row(4 * tau + 2, 2, B.g2, sc, sa, sb, false);
-          P.row(4 * tau + 3, 3, B.g3, sa, sb, sc, Fb);     // produces lattice row 4*tau, in tile row tau
+          P.row(4 * tau + 3, 3, B.g3, sa, sb, sc, __builtin_amdgcn_inverse_ballot_w64(Fb));     // produces lattice row 4*tau, in tile row tau
           if (PRIO) __builtin_amdgcn_s_setprio(0);
 #ifdef RCC_BAND_TRACE
           tr_act += wall_clock64() - tr_b; ++tr_na;
@@ -254,7 +255,7 @@ __device__ __forceinline__ void dense_band_body(const uint8_t* __restrict__ grey
 #pragma unroll
   for (int d = 0; d < BAND_DEPTH; ++d) issue_dma(t + d, d);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  bool F0 = allow_skip != 0, F1 = F0, F2 = F0;
+  mask64 F0 = allow_skip ? ~0ull : 0ull, F1 = F0, F2 = F0;
   const int tend = t1 + 2;                                // the back stage lags the front by two tile rows
   for (;;) {
     do_tile(t, H0, H1, H2, F0, F1, F2, S0, S1, S2);

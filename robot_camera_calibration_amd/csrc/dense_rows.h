@@ -21,6 +21,9 @@ __device__ __forceinline__ int from_right(int v, int edge) { return __builtin_am
 // zero for lanes without a source (bound_ctrl:0): lets the compiler fold the move into the consumer
 __device__ __forceinline__ int from_left0(int v) { return __builtin_amdgcn_update_dpp(0, v, DPP_FROM_LEFT, 0xf, 0xf, true); }
 __device__ __forceinline__ int from_right0(int v) { return __builtin_amdgcn_update_dpp(0, v, DPP_FROM_RIGHT, 0xf, 0xf, true); }
+// "does any lane hold c": the ballot compared as a scalar (hipcc's __any turns a lane mask into 0 / 1 per lane and compares
+// that: two vector instructions)
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 __device__ __forceinline__ i16x2 as_i(unsigned v) { return __builtin_bit_cast(i16x2, v); }
 __device__ __forceinline__ u16x2 as_u(unsigned v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ unsigned bits(i16x2 v) { return __builtin_bit_cast(unsigned, v); }
@@ -80,11 +83,11 @@ __device__ __forceinline__ TStat tile_stats(const Tile4& C)
     tmn = __builtin_elementwise_min(tmn, __builtin_elementwise_min(n0, n1));
     tmx = __builtin_elementwise_max(tmx, __builtin_elementwise_max(n0, n1));
   }
-  const int tmin = min((int)tmn.x, (int)tmn.y), tmax = max((int)tmx.x, (int)tmx.y);
+  const u16x2 nmn = (u16x2)(255) - tmn;                 // complemented while still packed: one instruction for both halves
+  const int nmin = max((int)nmn.x, (int)nmn.y), tmax = max((int)tmx.x, (int)tmx.y);
   // neighbours by DPP with zero fill for the lanes that have none: harmless for a maximum of non-negative values, so
   // the minimum is taken as the maximum of 255 - v.  Each max folds its DPP source (v_max_i32_dpp): 2 + 4 instructions
   // instead of 4 copies + 4 DPP moves + min3 / max3.
-  const int nmin = 255 - tmin;
   TStat hn;
   int m1 = max(tmax, from_left0(tmax)), n1 = max(nmin, from_left0(nmin));
   asm volatile("" : "+v"(m1), "+v"(n1));       // keeps the two maxima apart: as v_max3 the DPP sources become two moves
@@ -208,7 +211,7 @@ struct RowPipe {
       // selection on lattice row yc = rho - 4 = r - 5 (rows Ra = yc-2, Rb = yc, Rn = yc+2)
       const int yc = r - 5;
       const bool rowok = (yc >= 4 * t0) && (yc < 4 * t1) && (yc >= margin) && (yc < h - margin);
-      if (rowok && __any((Rb.r0 >= hthresh) || (Rb.r2 >= hthresh))) {
+      if (rowok && wave_any((Rb.r0 >= hthresh) || (Rb.r2 >= hthresh))) {
         // the neighbour lanes' responses, here only (the branch is wave-uniform: every lane is live for the DPP moves);
         // lanes 0 / 63 (halo, never selected) see 0 instead of a neighbour
         const int RaL = from_left0_here(Ra.r2), RbL = from_left0_here(Rb.r2), RnL = from_left0_here(Rn.r2);

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_dense_march(const uint8_t* __restrict__
     const int tau = t - 2;
     if (tau >= t0 - 2) {
       const bool out_row = (tau >= t0) && (tau < t1) && lane_out;
-      if (__any(lane_core && !(Fa && Fb && Fn))) {   // halo lanes do not vote: nothing they hold reaches an output
+      if (wave_any(lane_core && !(Fa && Fb && Fn))) {   // halo lanes do not vote: nothing they hold reaches an output
         if (out_row) {
           const Thr4 thr(thrB, flatB);
           store_row(4 * tau + 0, thr(Bc.g0));
