@@ -333,9 +333,12 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
     __builtin_amdgcn_raw_buffer_store_b32(lo | hi, ro, out_off, 0, 2 /* nt */);
   };
 
-  // software pipeline, two frames of loads in flight: at step f the loads of f+2 are issued, the
-  // taps of f are taken from LDS buffer f&1, and frame f+1 (loaded two steps ago) is converted
-  // into buffer (f+1)&1.  Unrolled by two so the register sets keep static names.
+  // software pipeline: at step f the loads of f+2 are issued, the taps of f are taken from LDS buffer f&1, and frame
+  // f+1 (loaded two steps ago) is converted into buffer (f+1)&1.  Unrolled by two so the register sets keep static names.
+  // (The loads sit behind wave-uniform branches -- slot_any -- so hipcc cannot count them and waits with vmcnt(1) before
+  // each conversion, i.e. also for the loads just issued.  Instantiating the loop per slot count makes the counts static
+  // (vmcnt(2..6)) and costs 8 registers: measured the same 1.67 ms per 1024 x 1080p -- the pass is not short of loads in
+  // flight, its waves wait for an issue slot half of their life (SQ_WAIT_INST_ANY) -- so the simple form stays.)
   uint8_t* const b0 = sbuf[0];
   uint8_t* const b1 = sbuf[1];
   Regs r0, r1;
