@@ -450,6 +450,7 @@ def main():
         print(json.dumps(out))
     det.close()
     if dist is not None:
+        dist.barrier()          # rank 0's roofline legs run after the timed region: every rank leaves together
         dist.destroy_process_group()
     return 0
 
