@@ -180,7 +180,9 @@ int  rcc_abi_version(void);
  *   det        out, capacity nframes*max_targets records, host memory; *ndet receives the count,
  *              records ordered by (frame, slot)
  *   corners    out, optional (may be NULL): nframes records, host memory
- *   stream     hipStream_t or NULL for the handle's own stream
+ *   stream     hipStream_t or NULL for the handle's own stream.  The handle's stream is a non-blocking one: it is NOT
+ *              ordered after work the caller has queued elsewhere (not even on the null stream), so device inputs
+ *              produced on another stream must be complete before the call, or the call must be given that stream
  * The call is synchronous with respect to its outputs. */
 int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t frames_mem,
                      rcc_detection* det, int32_t* ndet, rcc_frame_corners* corners, void* stream);

@@ -170,6 +170,18 @@ def _is_device(x):
     return hasattr(x, "is_cuda") and bool(x.is_cuda)
 
 
+def _after_torch(stream, *args):
+    """With stream=None the library works on the handle's own non-blocking stream, which is not ordered after torch's
+    current stream: wait for that stream first if any argument is a torch device tensor (a no-op when it is idle)."""
+    if stream is not None:
+        return
+    for x in args:
+        if _is_device(x):
+            import torch
+            torch.cuda.current_stream(x.device).synchronize()
+            return
+
+
 CAND_DT = np.dtype([("x", np.int16), ("y", np.int16), ("score", np.int32)])
 # numpy mirrors of the result records (same layout as abi.rcc_detection / abi.rcc_frame_corners)
 DET_DT = np.dtype([("frame", "<i4"), ("id", "<i4"), ("hamming", "<i4"), ("ncorners", "<i4"), ("size", "<f8"),
@@ -227,6 +239,7 @@ class Detector:
         det = np.zeros(max(nframes * self.cfg.max_targets, 1), DET_DT)
         fc = np.zeros(max(nframes, 1), FC_DT) if want_corners else None
         ndet = C.c_int32(0)
+        _after_torch(stream, frames)
         st = self._L.rcc_detect_batch(self._h, _ptr(frames), nframes, mem, _ptr(det), C.byref(ndet),
                                       _ptr(fc), _ptr(stream))
         self._chk(st, "rcc_detect_batch")
@@ -241,6 +254,7 @@ class Detector:
         if mem == abi.RCC_MEM_HOST and isinstance(frames, np.ndarray):
             frames = np.ascontiguousarray(frames)
         fc = np.zeros(max(nframes, 1), FC_DT) if want_corners else None
+        _after_torch(stream, frames)
         self._chk(self._L.rcc_detect_batch_submit(self._h, _ptr(frames), nframes, mem, _ptr(fc), _ptr(stream)), "rcc_detect_batch_submit")
         if not hasattr(self, "_pending"):
             self._pending = []
@@ -293,9 +307,11 @@ class Detector:
 
     # ---- stage-level (device pointers) -----------------------------------------------------------
     def stage_ingest(self, d_frames, nframes, d_grey, stream=None):
+        _after_torch(stream, d_frames, d_grey)
         self._chk(self._L.rcc_stage_ingest(self._h, _ptr(d_frames), nframes, _ptr(d_grey), _ptr(stream)), "rcc_stage_ingest")
 
     def stage_threshold_corner(self, d_grey, nframes, d_bin, d_cand, d_count, stream=None):
+        _after_torch(stream, d_grey, d_bin, d_cand, d_count)
         self._chk(self._L.rcc_stage_threshold_corner(self._h, _ptr(d_grey), nframes, _ptr(d_bin), _ptr(d_cand),
                                                      _ptr(d_count), _ptr(stream)), "rcc_stage_threshold_corner")
 
@@ -303,6 +319,7 @@ class Detector:
         det = np.zeros(max(nframes * self.cfg.max_targets, 1), DET_DT)
         fc = np.zeros(max(nframes, 1), FC_DT) if want_corners else None
         ndet = C.c_int32(0)
+        _after_torch(stream, d_grey, d_bin, d_cand, d_count)
         st = self._L.rcc_stage_targets(self._h, _ptr(d_grey), _ptr(d_bin), _ptr(d_cand), _ptr(d_count), nframes,
                                        _ptr(det), C.byref(ndet), _ptr(fc), _ptr(stream))
         self._chk(st, "rcc_stage_targets")
@@ -362,17 +379,20 @@ class Detector:
 
     def time_dense(self, d_grey, nframes, d_bin, d_cand, d_count, reps):
         ms = C.c_float(0)
+        _after_torch(None, d_grey, d_bin, d_cand, d_count)
         self._chk(self._L.rcc_time_dense(self._h, _ptr(d_grey), nframes, _ptr(d_bin), _ptr(d_cand), _ptr(d_count),
                                          reps, C.byref(ms)), "rcc_time_dense")
         return float(ms.value)
 
     def time_ingest(self, d_frames, nframes, d_grey, reps):
         ms = C.c_float(0)
+        _after_torch(None, d_frames, d_grey)
         self._chk(self._L.rcc_time_ingest(self._h, _ptr(d_frames), nframes, _ptr(d_grey), reps, C.byref(ms)), "rcc_time_ingest")
         return float(ms.value)
 
     def synth_render(self, sp, poses, d_frames, first_index=0, stream=None):
         poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 6)
+        _after_torch(stream, d_frames)
         self._chk(self._L.rcc_synth_render_batch(self._h, C.byref(sp), _ptr(poses), len(poses), first_index,
                                                  _ptr(d_frames), _ptr(stream)), "rcc_synth_render_batch")
 
