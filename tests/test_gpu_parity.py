@@ -335,6 +335,78 @@ def test_kernel_variants_bit_identical(torch_cuda, oracle, pixfmt, w, h, n):
     det.close()
 
 
+def _adversarial_grey(rng, w, h):
+    """grey images built to hit the corners of the integer arithmetic of the threshold + corner pass"""
+    yy, xx = np.mgrid[0:h, 0:w]
+    imgs = []
+    imgs.append(rng.integers(0, 256, (h, w), dtype=np.uint8))                               # full-range noise: largest gradients everywhere
+    imgs.append((((xx + yy) & 1) * 255).astype(np.uint8))                                   # 1-px checker of 0 / 255
+    imgs.append(np.full((h, w), 255, np.uint8)); imgs.append(np.zeros((h, w), np.uint8))    # saturated / empty
+    imgs.append((254 + ((xx // 3 + yy // 5) & 1)).astype(np.uint8))                         # 254 / 255 only: level 254, compare against 255
+    imgs.append(((xx // 4 + yy // 4) & 1).astype(np.uint8))                                 # 0 / 1 only: level 0
+    imgs.append((((xx // 8 + yy // 8) & 1) * 255).astype(np.uint8))                         # 8-px checker: X-junctions at full contrast
+    ramp = ((xx * 255) // max(w - 1, 1)).astype(np.uint8); imgs.append(ramp)                # slow ramp: flat / not flat boundary moves across tiles
+    blocks = rng.integers(0, 256, (h // 4 + 1, w // 4 + 1), dtype=np.uint8).repeat(4, 0).repeat(4, 1)[:h, :w]
+    imgs.append(blocks)                                                                      # piecewise constant on the tile lattice
+    mix = blocks.copy(); m = rng.random((h, w)) < 0.02; mix[m] = rng.integers(0, 256, int(m.sum()), dtype=np.uint8)
+    imgs.append(mix)                                                                         # isolated outliers
+    return np.stack(imgs)
+
+
+@pytest.mark.parametrize("w,h,contrast", [(640, 480, 32), (1920, 1080, 32), (1920, 1080, 1), (2064, 1080, 5)])
+def test_threshold_corner_adversarial_inputs(torch_cuda, oracle, w, h, contrast):
+    """saturated, two-level, full-range-noise and tile-lattice images through every variant of the pass (band kernel with
+    and without the flat-row skip, strip march, two-kernel form, generic LDS tiles): binary image and candidate lists
+    bit-identical to each other and to the oracle; min_contrast 1 and 5 reach the level-254 and level-0 compares"""
+    torch = torch_cuda
+    rng = np.random.default_rng(w + 7 * h + contrast)
+    host = _adversarial_grey(rng, w, h)
+    n = len(host)
+
+    def mod(c):
+        c.undistort = 0                      # grey = the mono input, so the oracle's image stages see the same bytes
+        c.thr_min_contrast = contrast
+        c.harris_thresh = 4000000            # keeps the candidate lists of the noise images below the capacity
+    cfg = _make(mod, w=w, h=h, pixfmt=abi.RCC_PIX_MONO8, B=n)
+    det = api.Detector(cfg)
+    grey = torch.from_numpy(host.reshape(n, -1)).cuda()
+    px = w * h
+    outs = {}
+    for dv in DENSE_VARIANTS:
+        det.set_dense_variant(dv[0]); det.set_dense_skip(dv[1])
+        binm = torch.full((n, px), 0x55, dtype=torch.uint8, device="cuda:0")
+        cand = torch.zeros((n, cfg.max_candidates * 8), dtype=torch.uint8, device="cuda:0")
+        cnt = torch.zeros((n,), dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        det.stage_threshold_corner(grey, n, binm, cand, cnt)
+        c = cand.cpu().numpy().view(api.CAND_DT).reshape(n, cfg.max_candidates)
+        k = cnt.cpu().numpy()
+        outs[dv] = (binm.cpu().numpy(), [sorted_cands(c[f][:min(k[f], cfg.max_candidates)]) for f in range(n)], k)
+    ref = outs[DENSE_VARIANTS[0]]
+    assert set(np.unique(ref[0]).tolist()) <= {0, 127, 255}            # every pixel written, with a legal value
+    for key, o in outs.items():
+        assert (o[0] == ref[0]).all(), "binary image differs for variant %s" % (key,)
+        assert (o[2] == ref[2]).all(), "candidate counts differ for variant %s" % (key,)
+        for f in range(n):
+            if ref[2][f] <= cfg.max_candidates:
+                assert (o[1][f] == ref[1][f]).all(), "candidates differ for variant %s image %d" % (key, f)
+    # the form rcc_detect_batch runs (binary image kept as the per-tile level map, expanded on demand): same image, same counts
+    det.set_dense_variant(1); det.set_dense_skip(1); det.set_keep_binary(0)
+    det.detect(grey, n)
+    img = det.fetch_images(n)
+    assert (img["bin"].reshape(n, -1) == ref[0]).all() and (img["cand_count"] == ref[2]).all()
+    ctx = oracle.Context(cfg)
+    for f in range(n):
+        k, odet, ofc, st = ctx.detect(host[f].reshape(-1), f, stages=True)
+        assert (st["grey"] == host[f]).all()
+        assert (ref[0][f].reshape(h, w) == st["bin"]).all(), "binary image differs from the oracle (image %d)" % f
+        assert ref[2][f] == st["ncand"], "candidate count differs from the oracle (image %d)" % f
+        if st["ncand"] <= cfg.max_candidates:
+            assert (ref[1][f]["x"] == st["cand"]["x"]).all() and (ref[1][f]["y"] == st["cand"]["y"]).all() and (ref[1][f]["score"] == st["cand"]["score"]).all()
+    ctx.close()
+    det.close()
+
+
 @pytest.mark.parametrize("w,h,n", [(640, 480, 6), (1920, 1080, 3), (3840, 2160, 2)])
 def test_compact_threshold_map_identical(torch_cuda, w, h, n):
     """detect() leaves the binary image as a per-tile threshold map by default; with rcc_set_keep_binary(1) it
