@@ -212,6 +212,42 @@ def test_fisheye_ingest_bit_exact(torch_cuda, oracle):
     det.close()
 
 
+@pytest.mark.parametrize("model,coeffs,w,h", [
+    (abi.RCC_DIST_PLUMB_BOB, abi.PLUMB_BOB_DEFAULT, 1920, 1080),
+    (abi.RCC_DIST_PLUMB_BOB, (-0.45, 0.25, 3e-3, -2e-3, -0.05), 1280, 720),     # strong: source boxes that do not fit the LDS stage take the gather path
+    (abi.RCC_DIST_PLUMB_BOB, (0.35, 0.1, 0.0, 0.0, 0.0), 1280, 720),            # pincushion: the map leaves the image (border constant 0)
+    (abi.RCC_DIST_FISHEYE, (-0.2, 0.05, -0.01, 0.002), 1280, 720),
+    (abi.RCC_DIST_NONE, (), 640, 480)])
+def test_ingest_adversarial_inputs(torch_cuda, oracle, model, coeffs, w, h):
+    """undistort + grey on full-range noise and saturated colours, mild to strong distortion, all three forms of the pass
+    (gather, LDS-staged with the tabulated map, LDS-staged recomputing it): the same bytes, and the oracle's"""
+    torch = torch_cuda
+    rng = np.random.default_rng(w + h + int(model))
+    n = 4
+
+    def mod(c):
+        abi.set_distortion(c, model, coeffs)
+    cfg = _make(mod, w=w, h=h, B=n)
+    host = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    host[1] = 255                                                   # every product at its maximum
+    host[2][..., 0] = 255; host[2][..., 1] = 0; host[2][..., 2] = 255
+    yy, xx = np.mgrid[0:h, 0:w]
+    host[3] = (((xx + yy) & 1) * 255).astype(np.uint8)[..., None]   # 1-px checker: every bilinear tap matters
+    frames = torch.from_numpy(host.reshape(n, -1)).cuda()
+    det = api.Detector(cfg)
+    outs = []
+    for iv in (0, 1, 2):
+        det.set_ingest_variant(iv)
+        grey = torch.full((n, h * w), 0x55, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        det.stage_ingest(frames, n, grey)
+        outs.append(grey.cpu().numpy())
+    assert (outs[1] == outs[0]).all() and (outs[2] == outs[0]).all()
+    for f in range(n):
+        assert (outs[0][f].reshape(h, w) == oracle.ingest(cfg, host[f].reshape(-1))).all(), "grey differs from the oracle (image %d)" % f
+    det.close()
+
+
 def test_solve_pnp_batch_matches_oracle(torch_cuda, oracle):
     """the drop-in for camera_pose.cpp:163: 4-point tags with the reference's point layout"""
     rng = np.random.default_rng(3)
