@@ -9,7 +9,9 @@ order and meaning.  Everything computes in librcc_hip.so (hand-written HIP, gfx9
 CPU fallback -- a missing library or device raises.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -45,6 +47,14 @@ def load_library():
     if not os.path.exists(path):
         raise FileNotFoundError(
             "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()')" % path)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64, and whichever copy is loaded first serves
+    # both.  With the system copy first, torch finds no device afterwards ("No HIP GPUs are available"), so where torch is
+    # installed it is imported before this library is loaded (callers that never use torch lose ~1.5 s once).
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(path)
     P, I = C.c_void_p, C.c_int32
     L.rcc_abi_version.restype = C.c_int

@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Container-only generator of tests/golden/image_xcheck.npz: an INDEPENDENT derivation of the image stages a1-a5
+ in numpy / scipy.ndimage -- whole-array filters, reshapes and broadcasting instead of the oracle's
+pixel loops, np.sum instead of its 64-bin tree, np.arctan instead of its own arctangent -- on three small synthetic
+frames rendered here (not by the oracle's or the library's synthetic camera).
+
+What it pins: the oracle (tests/test_golden.py, CPU) and the HIP path (tests/test_gpu_parity.py, GPU) must both
+reproduce these arrays: grey, Q5 maps and remapped images, threshold images, candidate lists, suppressed lists bit for
+bit; refined corners to 1e-9 px (the summation order differs).  What it does not pin: that DESIGN.md section 3 is what
+the reference's external detector computes (it is not: SURVEY.md 8(c), parity unpinned) -- it only shows that two
+independent programs written from the same definitions agree, so a slip in either restatement would surface.
+
+Neither this script nor scipy travels to the GPU box; only the .npz does.  Usage: python tests/golden/make_image_xcheck.py
+"""
+import os
+import numpy as np
+from scipy import ndimage as ndi
+
+W, H = 320, 240
+INT32_MIN = -(1 << 31)
+P = dict(harris_thresh=200000, cand_margin=8, nms_radius=5, win=5, max_iter=30, eps=1e-3)
+
+
+# ---- inputs: perspective views of a 9x7-square board, 3x3 supersampled, tinted, blurred, noisy ---------------------------
+def render(seed, angle_deg, scale, tx, ty, persp, sigma, noise):
+    rng = np.random.default_rng(seed)
+    ss = 3
+    v, u = np.mgrid[0:H * ss, 0:W * ss]
+    u = (u + 0.5) / ss - 0.5
+    v = (v + 0.5) / ss - 0.5
+    a = np.deg2rad(angle_deg)
+    # image -> board plane (squares of side 1, board centred at the origin)
+    x = (u - tx) / scale
+    y = (v - ty) / scale
+    xr = np.cos(a) * x + np.sin(a) * y
+    yr = -np.sin(a) * x + np.cos(a) * y
+    d = 1.0 + persp[0] * xr + persp[1] * yr
+    bx = xr / d + 4.5
+    by = yr / d + 3.5
+    inside = (bx >= 0) & (bx < 9) & (by >= 0) & (by < 7)
+    quiet = (bx >= -1) & (bx < 10) & (by >= -1) & (by < 8)
+    black = ((np.floor(bx) + np.floor(by)) % 2 == 0) & inside
+    img = np.empty((H * ss, W * ss, 3))
+    img[...] = (128.0, 120.0, 135.0)
+    img[quiet] = (235.0, 230.0, 240.0)
+    img[black] = (20.0, 25.0, 18.0)
+    img = img.reshape(H, ss, W, ss, 3).mean(axis=(1, 3))
+    if sigma > 0:
+        img = np.stack([ndi.gaussian_filter(img[..., c], sigma) for c in range(3)], -1)
+    img = img + rng.normal(0.0, noise, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+# ---- a1 -----------------------------------------------------------------------------------------------------------------
+def grey_of(bgr):
+    b = bgr.astype(np.int64)
+    return ((1868 * b[..., 0] + 9617 * b[..., 1] + 4899 * b[..., 2] + 8192) >> 14).astype(np.uint8)
+
+
+# ---- a2: Q5 map of the destination grid and the fixed-point bilinear remap ---------------------------------------------
+def map_q5(K, model, D, w, h):
+    fx, fy, cx, cy = K[0], K[4], K[2], K[5]
+    v, u = np.mgrid[0:h, 0:w].astype(np.float64)
+    x = (u - cx) / fx
+    y = (v - cy) / fy
+    if model == 1:                                  # plumb-bob: kr in Horner form
+        k1, k2, p1, p2, k3 = D[:5]
+        r2 = x * x + y * y
+        kr = 1.0 + ((k3 * r2 + k2) * r2 + k1) * r2
+        _2xy = (2.0 * x) * y
+        xd = x * kr + p1 * _2xy + p2 * (r2 + 2.0 * (x * x))
+        yd = y * kr + p1 * (r2 + 2.0 * (y * y)) + p2 * _2xy
+        xs = fx * xd + cx
+        ys = fy * yd + cy
+    elif model == 2:                                # fisheye (OpenCV convention)
+        k1, k2, k3, k4 = D[:4]
+        r = np.sqrt(x * x + y * y)
+        th = np.arctan(r)
+        t2 = th * th
+        thd = th * (1.0 + (((k4 * t2 + k3) * t2 + k2) * t2 + k1) * t2)
+        s = np.where(r > 1e-8, thd / np.where(r > 1e-8, r, 1.0), 1.0)
+        xs = (fx * x) * s + cx
+        ys = (fy * y) * s + cy
+    else:
+        xs, ys = u, v
+    q = lambda t: np.clip(np.rint(t * 32.0), INT32_MIN, (1 << 31) - 1).astype(np.int64)
+    return q(xs), q(ys)
+
+
+def remap_q5(grey, X, Y):
+    h, w = grey.shape
+    g = np.zeros((h + 2, w + 2), np.int64)          # one ring of zeros: BORDER_CONSTANT 0 for taps just outside
+    g[1:-1, 1:-1] = grey
+    ix, iy, fx, fy = X >> 5, Y >> 5, X & 31, Y & 31
+
+    def tap(xx, yy):
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        return np.where(ok, g[np.clip(yy, -1, h) + 1, np.clip(xx, -1, w) + 1], 0)
+    acc = (32 - fx) * (32 - fy) * tap(ix, iy) + fx * (32 - fy) * tap(ix + 1, iy) + (32 - fx) * fy * tap(ix, iy + 1) + fx * fy * tap(ix + 1, iy + 1)
+    return ((acc + 512) >> 10).astype(np.uint8)
+
+
+# ---- a3 -----------------------------------------------------------------------------------------------------------------
+def threshold_tiles(grey, min_contrast):
+    h, w = grey.shape
+    assert h % 4 == 0 and w % 4 == 0
+    t = grey.reshape(h // 4, 4, w // 4, 4).astype(np.int64)
+    tmin, tmax = t.min(axis=(1, 3)), t.max(axis=(1, 3))
+    dmin = ndi.minimum_filter(tmin, size=3, mode="nearest")      # a replicated border tile is already in the window
+    dmax = ndi.maximum_filter(tmax, size=3, mode="nearest")
+    mn = np.kron(dmin, np.ones((4, 4), np.int64))
+    mx = np.kron(dmax, np.ones((4, 4), np.int64))
+    out = np.where(grey.astype(np.int64) > mn + (mx - mn) // 2, 255, 0)
+    return np.where(mx - mn < min_contrast, 127, out).astype(np.uint8)
+
+
+# ---- a4.1 ---------------------------------------------------------------------------------------------------------------
+def harris_response(grey):
+    h, w = grey.shape
+    g = grey.astype(np.int64)
+    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]])
+    gx = ndi.correlate(g, kx, mode="constant") >> 3              # arithmetic shift = floor
+    gy = ndi.correlate(g, kx.T, mode="constant") >> 3
+    gx[[0, -1], :] = 0; gx[:, [0, -1]] = 0; gy[[0, -1], :] = 0; gy[:, [0, -1]] = 0
+    box = np.ones((5, 5), np.int64)
+    A = ndi.correlate(gx * gx, box, mode="constant") >> 4
+    B = ndi.correlate(gx * gy, box, mode="constant") >> 4
+    C = ndi.correlate(gy * gy, box, mode="constant") >> 4
+    Rf = A * C - B * B - (((A + C) ** 2) >> 4)
+    R = np.full((h, w), INT32_MIN, np.int64)
+    ys, xs = np.arange(4, h - 3, 2), np.arange(4, w - 3, 2)
+    R[np.ix_(ys, xs)] = Rf[np.ix_(ys, xs)]
+    assert R.max() < (1 << 31)
+    return R
+
+
+def harris_candidates(R, thresh, margin):
+    h, w = R.shape
+    margin = max(margin, 6)
+    m0 = (margin + 1) & ~1
+    ys, xs = np.arange(m0, h - margin, 2), np.arange(m0, w - margin, 2)
+    yy, xx = np.meshgrid(ys, xs, indexing="ij")
+    r = R[yy, xx]
+    ok = r >= thresh
+    for dy, dx, strict in ((-2, -2, 1), (-2, 0, 1), (-2, 2, 1), (0, -2, 1), (0, 2, 0), (2, -2, 0), (2, 0, 0), (2, 2, 0)):
+        nb = R[yy + dy, xx + dx]
+        ok &= (r > nb) if strict else (r >= nb)
+    sel = np.argwhere(ok)                                        # row-major = (y, x) order
+    return np.array([(xs[j], ys[i], r[i, j]) for i, j in sel], np.int64).reshape(-1, 3)
+
+
+# ---- a4.2 ---------------------------------------------------------------------------------------------------------------
+def suppress(c, radius):
+    if len(c) == 0:
+        return c
+    x, y, s = c[:, 0], c[:, 1], c[:, 2]
+    near = (np.abs(x[:, None] - x[None, :]) <= radius) & (np.abs(y[:, None] - y[None, :]) <= radius)
+    idx = np.arange(len(c))
+    beats = (s[None, :] > s[:, None]) | ((s[None, :] == s[:, None]) & (idx[None, :] < idx[:, None]))
+    np.fill_diagonal(near, False)
+    return c[~(near & beats).any(axis=1)]
+
+
+# ---- a5 -----------------------------------------------------------------------------------------------------------------
+def corner_subpix(grey, pts, win, max_iter, eps):
+    h, w = grey.shape
+    g = grey.astype(np.float64)
+    k = np.arange(-win, win + 1, dtype=np.float64)
+    m1 = np.exp(-((k / win) ** 2))
+    mask = m1[:, None] * m1[None, :]
+    px, py = np.meshgrid(k, k)                                   # px = column offset, py = row offset
+    out = np.zeros((len(pts), 2))
+    for q, (x0, y0) in enumerate(pts[:, :2].astype(np.float64)):
+        cx, cy = x0, y0
+        bad = False
+        for it in range(max_iter):
+            ix, iy = int(np.floor(cx)), int(np.floor(cy))
+            if ix - win - 1 < 0 or iy - win - 1 < 0 or ix + win + 2 > w - 1 or iy + win + 2 > h - 1:
+                bad = True
+                break
+            fx, fy = cx - ix, cy - iy
+            p = g[iy - win - 1: iy + win + 3, ix - win - 1: ix + win + 3]          # (2 win + 4)^2 pixels
+            S = (1 - fx) * (1 - fy) * p[:-1, :-1] + fx * (1 - fy) * p[:-1, 1:] + (1 - fx) * fy * p[1:, :-1] + fx * fy * p[1:, 1:]
+            gx = S[1:-1, 2:] - S[1:-1, :-2]
+            gy = S[2:, 1:-1] - S[:-2, 1:-1]
+            a = np.sum(gx * gx * mask); b = np.sum(gx * gy * mask); c = np.sum(gy * gy * mask)
+            bb1 = np.sum(mask * (gx * gx * px + gx * gy * py)); bb2 = np.sum(mask * (gx * gy * px + gy * gy * py))
+            det = a * c - b * b
+            if abs(det) <= np.finfo(float).eps ** 2:
+                break
+            dx, dy = (c * bb1 - b * bb2) / det, (a * bb2 - b * bb1) / det
+            cx, cy = cx + dx, cy + dy
+            if cx < 0 or cx >= w or cy < 0 or cy >= h:
+                break
+            if dx * dx + dy * dy <= eps * eps:
+                break
+        if bad or abs(cx - x0) > win or abs(cy - y0) > win:
+            cx, cy = x0, y0
+        out[q] = (cx, cy)
+    return out
+
+
+def main():
+    views = [dict(seed=1, angle_deg=12.0, scale=21.0, tx=158.0, ty=121.0, persp=(0.012, -0.008), sigma=0.7, noise=1.5),
+             dict(seed=2, angle_deg=-33.0, scale=17.5, tx=170.0, ty=112.0, persp=(-0.02, 0.015), sigma=1.0, noise=2.5),
+             dict(seed=3, angle_deg=78.0, scale=14.0, tx=150.0, ty=126.0, persp=(0.0, 0.025), sigma=0.5, noise=4.0)]
+    frames = np.stack([render(**v) for v in views])
+    grey = np.stack([grey_of(f) for f in frames])
+    out = dict(frames=frames, grey=grey, **{k: np.array(v) for k, v in P.items()})
+    out["bin32"] = np.stack([threshold_tiles(g, 32) for g in grey])
+    out["bin5"] = np.stack([threshold_tiles(g, 5) for g in grey])
+    cands, pres, xys = [], [], []
+    for g in grey:
+        R = harris_response(g)
+        c = harris_candidates(R, P["harris_thresh"], P["cand_margin"])
+        p = suppress(c, P["nms_radius"])
+        cands.append(c); pres.append(p); xys.append(corner_subpix(g, p, P["win"], P["max_iter"], P["eps"]))
+    out["cand"] = np.concatenate(cands); out["cand_n"] = np.array([len(c) for c in cands])
+    out["pre"] = np.concatenate(pres); out["pre_n"] = np.array([len(p) for p in pres])
+    out["pre_xy"] = np.concatenate(xys)
+    K = np.array([0.9 * W, 0.0, (W - 1) * 0.5, 0.0, 0.9 * W, (H - 1) * 0.5, 0.0, 0.0, 1.0])
+    cams = [(1, np.array([-0.28, 0.07, 2e-4, -1e-4, 0.0, 0, 0, 0])), (1, np.array([-0.45, 0.25, 3e-3, -2e-3, -0.05, 0, 0, 0])),
+            (2, np.array([-0.2, 0.05, -0.01, 0.002, 0, 0, 0, 0]))]
+    out["K"] = K
+    out["cam_model"] = np.array([m for m, _ in cams]); out["cam_D"] = np.stack([d for _, d in cams])
+    maps = [map_q5(K, m, d, W, H) for m, d in cams]
+    out["map_x"] = np.stack([m[0] for m in maps]).astype(np.int32); out["map_y"] = np.stack([m[1] for m in maps]).astype(np.int32)
+    out["remapped"] = np.stack([remap_q5(grey[0], mx, my) for mx, my in maps])
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "image_xcheck.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes; candidates", out["cand_n"], "suppressed", out["pre_n"],
+          "flat fraction", [float((b == 127).mean().round(3)) for b in out["bin32"]])
+
+
+if __name__ == "__main__":
+    main()
