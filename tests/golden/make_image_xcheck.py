@@ -200,6 +200,38 @@ def corner_subpix(grey, pts, win, max_iter, eps):
     return out
 
 
+# ---- a4.3 + a6: where the 8 x 6 inner corners of each view lie, and in which order they must be reported ------------------
+def ideal_corners(view, cols=8, rows=6):
+    """image positions of the inner corners from the view's own projective map (the inverse of render's), ordered by
+    DESIGN.md section 3 (a6): index = row * cols + col, columns along the board's long axis, (column, row) right-handed in
+    the image (x right, y down), and of the two labelings that leaves (the board is 180-degree symmetric) the one whose
+    corner 0 precedes its last corner in (y, x) order"""
+    a = np.deg2rad(view["angle_deg"])
+    p0, p1 = view["persp"]
+
+    def fwd(bx, by):
+        X, Y = bx - 4.5, by - 3.5
+        d = 1.0 / (1.0 - p0 * X - p1 * Y)
+        xr, yr = X * d, Y * d
+        x, y = np.cos(a) * xr - np.sin(a) * yr, np.sin(a) * xr + np.cos(a) * yr
+        return np.array([x * view["scale"] + view["tx"], y * view["scale"] + view["ty"]])
+    grid = np.array([[fwd(1.0 + c, 1.0 + r) for c in range(cols)] for r in range(rows)])     # [row][col] in board order
+    best = None
+    for flip in (False, True):
+        g = grid[::-1, ::-1] if flip else grid
+        cdir, rdir = g[0, cols - 1] - g[0, 0], g[rows - 1, 0] - g[0, 0]
+        if cdir[0] * rdir[1] - cdir[1] * rdir[0] < 0:
+            g = g[:, ::-1]                                                                    # mirror the columns: right-handed
+        pts = g.reshape(-1, 2)
+        first, last = pts[0], pts[-1]
+        ok = (round(first[1]), round(first[0])) < (round(last[1]), round(last[0]))
+        if ok:
+            assert best is None
+            best = pts
+    assert best is not None
+    return best
+
+
 def main():
     views = [dict(seed=1, angle_deg=12.0, scale=21.0, tx=158.0, ty=121.0, persp=(0.012, -0.008), sigma=0.7, noise=1.5),
              dict(seed=2, angle_deg=-33.0, scale=17.5, tx=170.0, ty=112.0, persp=(-0.02, 0.015), sigma=1.0, noise=2.5),
@@ -218,6 +250,7 @@ def main():
     out["cand"] = np.concatenate(cands); out["cand_n"] = np.array([len(c) for c in cands])
     out["pre"] = np.concatenate(pres); out["pre_n"] = np.array([len(p) for p in pres])
     out["pre_xy"] = np.concatenate(xys)
+    out["ideal_xy"] = np.stack([ideal_corners(v) for v in views])
     K = np.array([0.9 * W, 0.0, (W - 1) * 0.5, 0.0, 0.9 * W, (H - 1) * 0.5, 0.0, 0.0, 1.0])
     cams = [(1, np.array([-0.28, 0.07, 2e-4, -1e-4, 0.0, 0, 0, 0])), (1, np.array([-0.45, 0.25, 3e-3, -2e-3, -0.05, 0, 0, 0])),
             (2, np.array([-0.2, 0.05, -0.01, 0.002, 0, 0, 0, 0]))]
