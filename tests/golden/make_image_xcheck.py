@@ -232,6 +232,47 @@ def ideal_corners(view, cols=8, rows=6):
     return best
 
 
+# ---- square fiducials: an 8 x 8-cell tag drawn from its code word, and where its corners must be reported -----------------
+FW, FH = 640, 480
+
+
+def render_tags(codes, placements, seed=11, noise=1.5, sigma=0.6):
+    """placements: (index into codes, centre x, centre y, cell size in px, rotation in degrees, (p0, p1) perspective).
+    Tag frame: (c, r) in [0, 8]^2, origin at the printed tag's top-left corner, c to the right, r downwards; cell (r, c)
+    is black on the one-cell border, else white iff bit 35 - ((r - 1) * 6 + (c - 1)) of the code word is set (payload
+    row-major, MSB first).  Returns the frame and, per tag, its corners bl, br, tr, tl in image coordinates."""
+    rng = np.random.default_rng(seed)
+    ss = 3
+    v, u = np.mgrid[0:FH * ss, 0:FW * ss]
+    u = (u + 0.5) / ss - 0.5
+    v = (v + 0.5) / ss - 0.5
+    img = np.full((FH * ss, FW * ss), 225.0)
+    corners = []
+    for k, cx, cy, cell, ang, (p0, p1) in placements:
+        a = np.deg2rad(ang)
+        x, y = (u - cx) / cell, (v - cy) / cell
+        xr, yr = np.cos(a) * x + np.sin(a) * y, -np.sin(a) * x + np.cos(a) * y
+        d = 1.0 + p0 * xr + p1 * yr
+        c, r = xr / d + 4.0, yr / d + 4.0
+        inside = (c >= 0) & (c < 8) & (r >= 0) & (r < 8)
+        ci, ri = np.clip(np.floor(c).astype(int), 0, 7), np.clip(np.floor(r).astype(int), 0, 7)
+        bits = np.zeros((8, 8), bool)
+        for rr in range(6):
+            for cc in range(6):
+                bits[rr + 1, cc + 1] = (int(codes[k]) >> (35 - (rr * 6 + cc))) & 1
+        img[inside & ~bits[ri, ci]] = 25.0
+
+        def fwd(c_, r_):
+            X, Y = c_ - 4.0, r_ - 4.0
+            dd = 1.0 / (1.0 - p0 * X - p1 * Y)
+            xr_, yr_ = X * dd, Y * dd
+            return [(np.cos(a) * xr_ - np.sin(a) * yr_) * cell + cx, (np.sin(a) * xr_ + np.cos(a) * yr_) * cell + cy]
+        corners.append([fwd(0, 8), fwd(8, 8), fwd(8, 0), fwd(0, 0)])            # bl, br, tr, tl
+    img = img.reshape(FH, ss, FW, ss).mean(axis=(1, 3))
+    img = ndi.gaussian_filter(img, sigma) + rng.normal(0.0, noise, (FH, FW))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8), np.array(corners)
+
+
 def main():
     views = [dict(seed=1, angle_deg=12.0, scale=21.0, tx=158.0, ty=121.0, persp=(0.012, -0.008), sigma=0.7, noise=1.5),
              dict(seed=2, angle_deg=-33.0, scale=17.5, tx=170.0, ty=112.0, persp=(-0.02, 0.015), sigma=1.0, noise=2.5),
@@ -259,6 +300,12 @@ def main():
     maps = [map_q5(K, m, d, W, H) for m, d in cams]
     out["map_x"] = np.stack([m[0] for m in maps]).astype(np.int32); out["map_y"] = np.stack([m[1] for m in maps]).astype(np.int32)
     out["remapped"] = np.stack([remap_q5(grey[0], mx, my) for mx, my in maps])
+    fam = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "robot_camera_calibration_amd", "data", "family36b.txt")
+    codes = [int(l, 16) for l in open(fam) if l.strip() and not l.startswith("#")]
+    place = [(0, 110.0, 100.0, 11.0, 0.0, (0.0, 0.0)), (7, 300.0, 95.0, 9.0, 90.0, (0.01, 0.0)), (13, 500.0, 110.0, 12.0, 180.0, (0.0, -0.012)),
+             (21, 120.0, 330.0, 10.0, 270.0, (0.008, 0.008)), (34, 320.0, 320.0, 13.0, 37.0, (-0.01, 0.006)), (47, 520.0, 340.0, 9.5, -122.0, (0.0, 0.015))]
+    fid_frame, fid_corners = render_tags(codes, place)
+    out["fid_frame"] = fid_frame; out["fid_ids"] = np.array([p_[0] for p_ in place]); out["fid_corners"] = fid_corners
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "image_xcheck.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; candidates", out["cand_n"], "suppressed", out["pre_n"],
