@@ -201,7 +201,8 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
 bool rcc_dense_band_supported(const rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin);
 
 // variants: 0 = generic LDS tiles (any geometry), 1 = band kernel (k_dense_band.hip), 2 = strip march
-// (k_dense_fast.hip), 3 = band sweep + corner kernel on the active rows (k_dense_band.hip SPLIT + k_dense_runs.hip);
+// (k_dense_fast.hip), 3 = band sweep + corner kernel on the active rows (k_dense_band.hip SPLIT + k_dense_runs.hip),
+// 4 = one independent wavefront per window for the compact-map form (k_dense_wave.hip; the band kernel otherwise);
 // -1 = the fastest one the geometry allows.  All produce identical outputs.
 hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
                             rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s)
@@ -212,11 +213,11 @@ hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, u
   if (e != hipSuccess) return e;
   int variant = h->dense_variant;
   const bool band_ok = rcc_dense_band_supported(h, d_grey, d_bin), march_ok = rcc_dense_march_supported(h);
-  if (variant < 0) variant = band_ok ? 1 : (march_ok ? 2 : 0);
-  if ((variant == 1 || variant == 3) && !band_ok) variant = march_ok ? 2 : 0;
+  if (variant < 0) variant = band_ok ? 4 : (march_ok ? 2 : 0);     // 4: a wavefront per window where the compact map is asked for, else the band kernel
+  if ((variant == 1 || variant == 3 || variant == 4) && !band_ok) variant = march_ok ? 2 : 0;
   if (variant == 2 && !march_ok) variant = 0;
   h->bin_from_thr = 0;      // only the band kernel can leave the binary image as the compact threshold map
-  if (variant == 1 || variant == 3) return rcc_launch_dense_band(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s, variant == 3);
+  if (variant == 1 || variant == 3 || variant == 4) return rcc_launch_dense_band(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s, variant == 3 ? 1 : variant == 4 ? 2 : 0);
   if (variant == 2) { h->dense_kernel = "k_dense_march<0>"; return rcc_launch_dense_march(h, d_grey, nframes, d_bin, d_cand, d_cand_count, s); }
   h->dense_kernel = "k_dense_lds";
   const int w = c.width, ht = c.height;

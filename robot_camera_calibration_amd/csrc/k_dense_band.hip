@@ -161,7 +161,9 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
   nseg = (th + seg_tiles - 1) / seg_tiles;
   const int allow_skip = rcc_dense_allow_skip(h);
   h->bin_from_thr = thr ? 1 : 0;
-  if (split) {
+  // split == 2: one independent wavefront per window (k_dense_wave.hip) -- the compact-map form only
+  if (split == 2 && thr && rcc_dense_wave_supported(h, d_grey)) return rcc_launch_dense_wave(h, d_grey, nframes, d_cand, d_cand_count, s);
+  if (split == 1) {
     const int tp = rcc_flat_tp(ht);
     const size_t need = rcc_flat_index(h->cfg.batch_capacity > nframes ? h->cfg.batch_capacity : nframes, 0, 0, nbands, tp) * sizeof(unsigned long long);
     if (need > h->flat_bytes) {

@@ -1,0 +1,188 @@
+// k_dense_wave.hip -- variant 4 of the threshold + corner pass (a3 + a4.1), compact-map form only (what
+// rcc_detect_batch runs): ONE INDEPENDENT WAVEFRONT per (frame, segment, band, window), no workgroup barrier.
+//
+// Same definitions, same per-lane arithmetic (dense_rows.h) and bit-identical outputs as the band kernel
+// (k_dense_band.hip).  What changes is the unit of scheduling.  In the band kernel eight windows march in lockstep,
+// one s_barrier per tile row, because they share the staged rows: a wave whose window is flat waits at every barrier for
+// the waves that run the corner stages, and its slot is held until the whole workgroup retires.  The pass is bound by
+// vector-instruction issue, a wave alone issues at ~3/4 of the SIMD's rate, and the active
+// windows of a frame are always the same ones -- so what the lockstep costs is SIMDs on which too few waves are ready.
+// Here every window is its own 64-thread workgroup with its own 4-KiB ring in LDS:
+//   * per tile row the wave issues ONE LDS-DMA load (buffer_load_dwordx4 ... lds: its window's 4 rows x 256 B) and ONE
+//     byte store (its 61 tile levels); the corner stages re-read the rows from its ring; the 12 halo pixels a window
+//     shares with its neighbour are fetched twice (5 %, from L2);
+//   * a flat window runs ahead at the speed of the front stage alone and retires early; the dispatcher refills its slot
+//     with the next job, so a SIMD keeps six waves that all have work;
+//   * ordering is the wave's own: a counted s_waitcnt vmcnt(2 * WAVE_DEPTH - 1) before a staged tile row is read (every
+//     iteration issues exactly one DMA and one store, both unconditional -- a row or lane with nothing to write gets an
+//     out-of-range offset, which the hardware drops), no LDS traffic between waves at all.
+// The full binary image (stage form) stays with the band kernel: a window's 244-byte spans would be written as partial
+// 128-byte lines, one dword per lane and row -- built and measured: 1.64 ms per 1024 x 1080p against the band kernel's
+// 0.90 (scratch/membench3.hip had the stores alone at 0.58 ms against 0.36 ms for whole lines).
+#include "dense_band_body.h"
+
+#ifndef WAVE_DEPTH
+#define WAVE_DEPTH 1
+#endif
+#define WAVE_RING (WAVE_DEPTH + 3)
+
+template <int PRIO>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
+void k_dense_wave(const uint8_t* __restrict__ grey, int w, int h, int nbands, int nwin, int nseg, int seg_tiles, int nframes,
+                  int min_contrast, int hthresh, int margin, int cap, int allow_skip, uint8_t* __restrict__ thr_map,
+                  rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count, int fchunk)
+{
+  __shared__ __attribute__((aligned(1024))) uint8_t ring[WAVE_RING * 1024];
+  // workgroup -> job, as the band kernel deals them (an XCD takes chunks of consecutive frames along a diagonal); the
+  // windows of a band segment are consecutive jobs of one XCD, so the halo columns they share meet in its L2
+  const int jpf = nbands * nseg * nwin, cj = fchunk * jpf, k = (int)(blockIdx.x >> 3);
+  const int grp = k / cj, r = k - grp * cj;
+  const int f = (8 * grp + (((int)(blockIdx.x & 7u) - grp) & 7)) * fchunk + r / jpf;
+  if (f >= nframes) return;
+  const int jr = r % jpf;
+  const int wv = jr % nwin, band = (jr / nwin) % nbands, seg = jr / (nwin * nbands);
+  const int lane = threadIdx.x;
+  const int th = h >> 2;
+  const int t0 = seg * seg_tiles;
+  const int t1 = min(t0 + seg_tiles, th);
+  const int X0 = band * BAND_W, X1 = min(X0 + BAND_W, w);
+  if (X0 + wv * STRIP_USE >= X1 || t0 >= t1) return;          // window without band pixels / empty segment (uniform)
+  const int xw = X0 + wv * STRIP_USE - 8;                       // first pixel of the window
+  const int x0 = xw + 4 * lane;                                 // first pixel of this lane
+  const int xl = min(max(x0, 0), w - 4);                        // clamped column (as the strip and band kernels)
+  const bool lane_out = (lane >= 2) && (lane <= 62) && (x0 >= X0) && (x0 < X1);
+  const int xs = min(max(xw, 0), w - 256);                      // first staged column: 256 bytes that hold every clamped lane
+  if (margin < 6) margin = 6;
+
+  const uint8_t* gf = grey + (size_t)f * w * h;
+  const uint64_t ga = (uint64_t)(uintptr_t)gf;
+  i32x4 rs_g;
+  rs_g.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)ga);
+  rs_g.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(ga >> 32) & 0xFFFFu));
+  rs_g.z = w * h;
+  rs_g.w = 0x00020000;
+  uint8_t* bo = thr_map + ((size_t)f * nbands + band) * (size_t)th * RCC_THR_PITCH;
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(bo, 0, th * RCC_THR_PITCH, 0x00020000);
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ring);
+  const int dk = lane >> 4, di = lane & 15;                     // quarter-wave k moves row k, 16 B per lane
+  const int v_edge = xs + 16 * di, v_in = (int)__umul24((unsigned)dk, (unsigned)w) + v_edge;
+  const unsigned rd_off = (unsigned)(xl - xs);                  // + 256 k + slot
+  const int st_voff = lane_out ? ((x0 - X0) >> 2) : BAND_INVALID;
+
+  // tile row tt -> ring slot; rows clamped to the image (the height is a multiple of 4: a tile row is inside or outside)
+  auto issue_dma = [&](int tt, int slot) {
+    const bool inside = (tt >= 0) && (tt < th);
+    const int soff = __builtin_amdgcn_readfirstlane(inside ? 4 * tt * w : (tt < 0 ? 0 : (h - 1) * w));
+    dma_1k(rs_g, ring_lds + (unsigned)(slot * 1024), inside ? v_in : v_edge, soff);
+  };
+  auto read_tile = [&](int slot) -> Tile4 {
+    const uint8_t* p = ring + slot * 1024 + rd_off;
+    Tile4 T;
+    T.g0 = *reinterpret_cast<const unsigned*>(p);
+    T.g1 = *reinterpret_cast<const unsigned*>(p + 256);
+    T.g2 = *reinterpret_cast<const unsigned*>(p + 512);
+    T.g3 = *reinterpret_cast<const unsigned*>(p + 768);
+    return T;
+  };
+
+  SobelRow S0 = { 0, 0, 0, 0 }, S1 = S0, S2 = S0;
+  TStat H0 = { 255, 0 }, H1 = H0, H2 = H0;
+  RowPipe P;
+  P.reset();
+  P.w = w; P.h = h; P.t0 = t0; P.t1 = t1; P.margin = margin; P.hthresh = hthresh; P.cap = cap; P.f = f;
+  P.cand = cand; P.cand_count = cand_count;
+  P.set_lane(x0, lane, lane_out);
+  typedef unsigned long long mask64;
+  int thrB = 0;
+  mask64 flatB = ~0ull;
+  const mask64 core_lanes = 0x7FFFFFFFFFFFFFFCull;
+  int sf = 0;                                                   // ring slot of tile row t
+
+  auto do_tile = [&](const int t, const TStat& ha, const TStat& hb, TStat& hn,
+                     const mask64 Fa, const mask64 Fb, mask64& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
+    // tile row t has landed: the DMA that fetched it has 2 * WAVE_DEPTH - 1 younger operations of this wave
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * WAVE_DEPTH - 1) : "memory");
+    const int sd = (sf + WAVE_DEPTH >= WAVE_RING) ? sf + WAVE_DEPTH - WAVE_RING : sf + WAVE_DEPTH;
+    const int sb2 = (sf >= 2) ? sf - 2 : sf + WAVE_RING - 2;
+    issue_dma(t + WAVE_DEPTH, sd);        // the slot held tile row t-3, last read (and consumed) in iteration t-1
+    // ---- FRONT
+    hn = tile_stats(read_tile(sf));
+    const int dmin = min(ha.hmin, min(hb.hmin, hn.hmin)), dmax = max(ha.hmax, max(hb.hmax, hn.hmax));
+    const int range = dmax - dmin;
+    const int thrN = dmin + (range >> 1);
+    const mask64 flatN = __builtin_amdgcn_ballot_w64(range < min_contrast);
+    Fn = allow_skip ? (((t - 1) < t0 - 1) ? ~0ull : flatN) : 0ull;
+    // ---- BACK
+    const int tau = t - 2;
+    const int level = __builtin_amdgcn_inverse_ballot_w64(flatB) ? 255 : thrB;     // tile row tau's level
+    if (tau >= t0 - 2) {
+      if ((core_lanes & ~(Fa & Fb & Fn)) != 0ull) {
+        if (PRIO) __builtin_amdgcn_s_setprio(2);
+        const Tile4 B = read_tile(sb2);
+        P.row(4 * tau + 0, 0, B.g0, sa, sb, sc, false);
+        P.row(4 * tau + 1, 1, B.g1, sb, sc, sa, __builtin_amdgcn_inverse_ballot_w64(Fa));
+        P.row(4 * tau + 2, 2, B.g2, sc, sa, sb, false);
+        P.row(4 * tau + 3, 3, B.g3, sa, sb, sc, __builtin_amdgcn_inverse_ballot_w64(Fb));
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+      } else {
+        P.skip();
+        dontcare(sa); dontcare(sb); dontcare(sc);
+      }
+    }
+    // the one store of the iteration (dropped where there is nothing to write: the counted wait relies on its presence)
+    const bool ok = (tau >= t0) && (tau < t1);
+    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)level, rs_b, ok ? st_voff : BAND_INVALID,
+                                         __builtin_amdgcn_readfirstlane(ok ? tau * RCC_THR_PITCH : 0), 0);
+    thrB = thrN; flatB = flatN;
+    sf = (sf + 1 == WAVE_RING) ? 0 : sf + 1;
+  };
+
+  int t = t0 - 2;
+#pragma unroll
+  for (int d = 0; d < WAVE_DEPTH; ++d) issue_dma(t + d, d);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the loop's counted wait only reasons about its own operations
+  mask64 F0 = allow_skip ? ~0ull : 0ull, F1 = F0, F2 = F0;
+  const int tend = t1 + 2;
+  for (;;) {
+    do_tile(t, H0, H1, H2, F0, F1, F2, S0, S1, S2);
+    if (++t > tend) break;
+    do_tile(t, H1, H2, H0, F1, F2, F0, S1, S2, S0);
+    if (++t > tend) break;
+    do_tile(t, H2, H0, H1, F2, F0, F1, S2, S0, S1);
+    if (++t > tend) break;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // a DMA still in flight must not land in the next workgroup's LDS
+}
+
+bool rcc_dense_wave_supported(const rcc_handle* h, const uint8_t* d_grey)
+{
+  return rcc_dense_band_supported(h, d_grey, nullptr) && h->cfg.width >= 256;
+}
+
+int rcc_dense_allow_skip(const rcc_handle* h);
+
+hipError_t rcc_launch_dense_wave(rcc_handle* h, const uint8_t* d_grey, int nframes, rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s)
+{
+  const rcc_config& c = h->cfg;
+  const int nbands = (c.width + BAND_W - 1) / BAND_W;
+  const int bw = c.width < BAND_W ? c.width : BAND_W;
+  const int nwin = (bw + STRIP_USE - 1) / STRIP_USE;
+  const int fchunk = nframes >= 1024 ? 16 : nframes >= 64 ? nframes / 64 : 1;
+  // Segments: jobs are single waves, so the count only trades the four warm-up tile rows of a segment against the length
+  // of the longest chains at the end of the launch.  Measured on 1024 x 1080p (270 tile rows): 2 / 3 / 4 / 5 / 6 / 8 / 9 /
+  // 12 segments 0.79 / 0.76 / 0.73 / 0.70 / 0.72 / 0.69 / 0.71 / 0.73 ms -- about 34 tile rows per segment.
+  const int th = c.height >> 2;
+  int nseg = (th + 17) / 34;
+  if (nseg < 1) nseg = 1;
+  const int seg_tiles = (th + nseg - 1) / nseg;
+  nseg = (th + seg_tiles - 1) / seg_tiles;
+  const long long njobs = (long long)nbands * nseg * nwin * ((nframes + 8 * fchunk - 1) / (8 * fchunk)) * 8 * fchunk;
+#ifndef WAVE_PRIO
+#define WAVE_PRIO 0      // independent waves: nobody to get ahead of (measured the same with 1)
+#endif
+  h->dense_kernel = "k_dense_wave<0>";
+  hipLaunchKernelGGL((k_dense_wave<WAVE_PRIO>), dim3((unsigned)njobs), dim3(64), 0, s, d_grey, c.width, c.height, nbands, nwin, nseg, seg_tiles,
+                     nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, rcc_dense_allow_skip(h), h->d_thr,
+                     d_cand, d_cand_count, fchunk);
+  return hipGetLastError();
+}

@@ -264,7 +264,7 @@ static int ensure_bin(rcc_handle* h)
 // will rcc_launch_dense (with want_thr set) write d_thr instead of a full image?  (mirrors its variant choice)
 static bool detect_needs_bin(const rcc_handle* h)
 {
-  const bool band_variant = h->dense_variant < 0 || h->dense_variant == 1 || h->dense_variant == 3;
+  const bool band_variant = h->dense_variant < 0 || h->dense_variant == 1 || h->dense_variant == 3 || h->dense_variant == 4;
   return h->keep_bin || !band_variant || !rcc_dense_band_supported(h, h->d_grey, nullptr);
 }
 

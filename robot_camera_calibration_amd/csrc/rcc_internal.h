@@ -121,6 +121,8 @@ struct rcc_handle {
 
 // ---- launchers (each returns hipError_t of the launch) ---------------------------------------
 hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes, uint8_t* d_grey, hipStream_t s);
+bool rcc_dense_wave_supported(const rcc_handle* h, const uint8_t* d_grey);
+hipError_t rcc_launch_dense_wave(rcc_handle* h, const uint8_t* d_grey, int nframes, rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
 hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,
                             rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
 bool rcc_dense_band_supported(const rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin);

@@ -21,7 +21,7 @@ for s0 in range(0, B, 64):
 torch.cuda.synchronize()
 det.stage_ingest(frames, B, grey)
 ref = None
-for variant in (1, 3, 1, 3):
+for variant in [int(v) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else "1,3,1,3".split(","))]:
     det.set_dense_variant(variant)
     out = []
     for form, b in (("stage", binm), ("compact", None)):

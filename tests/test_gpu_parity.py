@@ -322,8 +322,9 @@ def test_edge_cases(torch_cuda, oracle):
         api.Detector(bad)
 
 
-# dense pass: (variant, flat-row skip) -- 0 generic LDS tiles, 1 band kernel, 2 strip march, 3 band sweep + corner kernel on the active rows
-DENSE_VARIANTS = ((0, 1), (1, 1), (1, 0), (2, 1), (2, 0), (3, 1), (3, 0))
+# dense pass: (variant, flat-row skip) -- 0 generic LDS tiles, 1 band kernel, 2 strip march, 3 band sweep + corner kernel on the active rows,
+# 4 one wavefront per window (compact-map form; the band kernel where the full image is asked for)
+DENSE_VARIANTS = ((0, 1), (1, 1), (1, 0), (2, 1), (2, 0), (3, 1), (3, 0), (4, 1), (4, 0))
 
 
 @pytest.mark.parametrize("pixfmt,w,h,n", [(abi.RCC_PIX_BGR8, 640, 480, 5), (abi.RCC_PIX_MONO8, 640, 480, 5),
@@ -427,10 +428,14 @@ def test_threshold_corner_adversarial_inputs(torch_cuda, oracle, w, h, contrast)
             if ref[2][f] <= cfg.max_candidates:
                 assert (o[1][f] == ref[1][f]).all(), "candidates differ for variant %s image %d" % (key, f)
     # the form rcc_detect_batch runs (binary image kept as the per-tile level map, expanded on demand): same image, same counts
-    det.set_dense_variant(1); det.set_dense_skip(1); det.set_keep_binary(0)
-    det.detect(grey, n)
-    img = det.fetch_images(n)
-    assert (img["bin"].reshape(n, -1) == ref[0]).all() and (img["cand_count"] == ref[2]).all()
+    for variant, skip in ((1, 1), (4, 1), (4, 0)):
+        det.set_dense_variant(variant); det.set_dense_skip(skip); det.set_keep_binary(0)
+        det.detect(grey, n)
+        img = det.fetch_images(n)
+        assert (img["bin"].reshape(n, -1) == ref[0]).all() and (img["cand_count"] == ref[2]).all(), (variant, skip)
+        for f in range(n):
+            if ref[2][f] <= cfg.max_candidates:
+                assert (sorted_cands(img["cand"][f][:ref[2][f]]) == ref[1][f]).all(), (variant, skip, f)
     ctx = oracle.Context(cfg)
     for f in range(n):
         k, odet, ofc, st = ctx.detect(host[f].reshape(-1), f, stages=True)
@@ -453,7 +458,7 @@ def test_compact_threshold_map_identical(torch_cuda, w, h, n):
     frames, _ = _render(torch, det, cfg, n, seed=77)
     torch.cuda.synchronize()
     ref = None
-    for variant in (1, 3):                 # fused band kernel; band sweep + corner kernel on the active rows
+    for variant in (1, 3, 4):              # fused band kernel; band sweep + corner kernel on the active rows; a wavefront per window
         det.set_dense_variant(variant)
         det.set_keep_binary(0)
         d0, f0 = det.detect(frames, n)

@@ -39,11 +39,11 @@ def listing():
     return open(out).read().split("\n")
 
 
-def _kernels(lines):
-    """{mangled name: [instruction / label lines]} for the k_dense_band* kernels"""
+def _kernels(lines, stem="k_dense_band"):
+    """{mangled name: [instruction / label lines]} for the kernels whose name starts with `stem`"""
     out, name = {}, None
     for l in lines:
-        m = re.match(r"^(_Z\d+k_dense_band\S*):", l)
+        m = re.match(r"^(_Z\d+%s\S*):" % stem, l)
         if m:
             name = m.group(1); out[name] = []; continue
         if name is None:
@@ -144,3 +144,56 @@ def test_guard_catches_a_broken_iteration(listing):
     cond = ins[:j] + ["s_cbranch_scc1 .LBB999_1", ins[j], ".LBB999_1:"] + ins[j + 1:]
     ev = _head_events(cond, b)
     assert not (ev[:1] == ["DMA"] and "ST" in ev and all(e in ("DMA", "ST", "cDMA") for e in ev)) or ev.index("ST") > 1, ev
+
+
+# ---- the wave-per-window kernel (csrc/k_dense_wave.hip): the same counted wait, no barrier -------------------------------
+@pytest.fixture(scope="module")
+def wave_listing():
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    out = os.path.join(CSRC, "k_dense_wave.isa.s")
+    deps = [os.path.join(CSRC, f) for f in ("k_dense_wave.hip", "dense_band_body.h", "dense_rows.h", "rcc_internal.h")]
+    if not os.path.exists(out) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(out):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                               "-o", out, os.path.join(CSRC, "k_dense_wave.hip")], stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
+
+
+def test_counted_wait_invariant_holds_in_the_compiled_wave_kernel(wave_listing):
+    """k_dense_wave: every wave is on its own, so a staged tile row is guarded by `s_waitcnt vmcnt(2 * WAVE_DEPTH - 1)` alone.
+    That needs, per unrolled iteration and on every path: the wait, then the LDS-DMA of the row WAVE_DEPTH ahead as the
+    first vector-memory operation, and ONE byte store of the tile levels after the corner stages have rejoined (more
+    operations -- the candidate path -- only make the wait stricter; fewer would let it pass early)."""
+    src = open(os.path.join(CSRC, "k_dense_wave.hip")).read()
+    depth = int(re.search(r"#define\s+WAVE_DEPTH\s+(\d+)", src).group(1))
+    want_wait = "s_waitcnt vmcnt(%d) lgkmcnt(0)" % (2 * depth - 1)
+    kernels = _kernels(wave_listing, "k_dense_wave")
+    assert len(kernels) >= 1
+    for name, ins in kernels.items():
+        assert not any(t.startswith("s_barrier") for t in ins), "%s: a barrier in the barrier-free kernel" % name
+        waits = [i for i, t in enumerate(ins) if t.replace("  ", " ") == want_wait]
+        stores = [i for i, t in enumerate(ins) if t.startswith("buffer_store_byte")]
+        dmas = [i for i, t in enumerate(ins) if _is_dma(t)]
+        assert len(waits) == 3 and len(stores) == 3, "%s: %d counted waits, %d level stores (the loop is unrolled by three)" % (name, len(waits), len(stores))
+        assert len(dmas) == 3 + depth, "%s: %d LDS-DMA instructions" % (name, len(dmas))
+        for n, wi in enumerate(waits):
+            # the first vector-memory operation after the wait is the DMA, before any branch
+            ev = _head_events(ins, wi)        # (scalar row-address selection compiles to short forward diamonds: followed)
+            assert ev[:1] == ["DMA"], "%s: iteration %d starts with %s" % (name, n, ev)
+            # exactly one level store before the next counted wait (or the loop's end), issued after the last join: no
+            # branch between the nearest label above it and the store, so no path skips it
+            nxt = waits[n + 1] if n + 1 < len(waits) else len(ins)
+            mine = [si for si in stores if wi < si < nxt]
+            assert len(mine) == 1, "%s: %d level stores in iteration %d" % (name, len(mine), n)
+            k = mine[0]
+            lab = max(i for i in range(wi, k) if _is_label(ins[i]))
+            assert not any(_is_branch(t) for t in ins[lab:k]), "%s: the level store of iteration %d sits behind a branch" % (name, n)
+        # no drain inside the loop except behind the candidate path's returning atomic; outright wait in the prologue, drain at the end
+        for i, t in enumerate(ins):
+            if t.startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", t) and waits[0] < i:
+                behind_atomic = any("atomic" in u for u in ins[max(0, i - 24):i])
+                before_end = any(u.startswith("s_endpgm") for u in ins[i:i + 8])
+                assert behind_atomic or before_end, "%s: '%s' inside the loop (instruction %d)" % (name, t, i)
+        assert any(t.startswith("s_waitcnt") and "vmcnt(0)" in t for t in ins[dmas[0]:waits[0]]), "%s: the prologue no longer waits outright" % name
+        ends = [i for i, t in enumerate(ins) if t.startswith("s_endpgm")]
+        assert ends and any(any(u.startswith("s_waitcnt") and "vmcnt(0)" in u for u in ins[max(0, e - 8):e]) for e in ends)
