@@ -22,15 +22,24 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // 64 lanes x 16 B, global -> LDS at lds_addr + 16 * lane; no VGPR destination.  M0 is saved and restored around
 // the instruction (it belongs to the compiler).
+template <bool NT = true>
 __device__ __forceinline__ void dma_1k(i32x4 rsrc, unsigned lds_addr, int voff, int soff)
 {
   unsigned keep;
   // nt: the grey image is read once by this pass and is far larger than the caches -- as a non-temporal stream it does not
-  // push the pass's own output lines out (measured with the nt stores below: stage form 1.03 -> 0.99 ms per 1024 x 1080p)
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory");
+  // push the pass's own output lines out (measured with the nt stores below: stage form 1.03 -> 0.99 ms per 1024 x 1080p).
+  // NT = false for the wave-per-window kernel, whose neighbouring windows share 128-byte lines: left to the L2, the second
+  // window's fetch hits there instead of going to HBM again.
+  if (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
 }
 
 // LDS bytes of one workgroup: the ring + the output stage

@@ -25,6 +25,9 @@
 #define WAVE_DEPTH 1
 #endif
 #define WAVE_RING (WAVE_DEPTH + 3)
+#ifndef WAVE_DMA_NT
+#define WAVE_DMA_NT false
+#endif
 
 template <int PRIO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
@@ -73,7 +76,7 @@ void k_dense_wave(const uint8_t* __restrict__ grey, int w, int h, int nbands, in
   auto issue_dma = [&](int tt, int slot) {
     const bool inside = (tt >= 0) && (tt < th);
     const int soff = __builtin_amdgcn_readfirstlane(inside ? 4 * tt * w : (tt < 0 ? 0 : (h - 1) * w));
-    dma_1k(rs_g, ring_lds + (unsigned)(slot * 1024), inside ? v_in : v_edge, soff);
+    dma_1k<WAVE_DMA_NT>(rs_g, ring_lds + (unsigned)(slot * 1024), inside ? v_in : v_edge, soff);
   };
   auto read_tile = [&](int slot) -> Tile4 {
     const uint8_t* p = ring + slot * 1024 + rd_off;
