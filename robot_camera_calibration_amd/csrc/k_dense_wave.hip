@@ -17,8 +17,9 @@
 //     iteration issues exactly one DMA and one store, both unconditional -- a row or lane with nothing to write gets an
 //     out-of-range offset, which the hardware drops), no LDS traffic between waves at all.
 // The full binary image (stage form) stays with the band kernel: a window's 244-byte spans would be written as partial
-// 128-byte lines, one dword per lane and row -- built and measured: 1.64 ms per 1024 x 1080p against the band kernel's
-// 0.90 (scratch/membench3.hip had the stores alone at 0.58 ms against 0.36 ms for whole lines).
+// 128-byte lines, one dword per lane and row -- built and measured: 1.55-1.64 ms per 1024 x 1080p with non-temporal
+// stores, 1.35 ms with cached ones, against the band kernel's 0.90-0.92 (scratch/membench3.hip had the stores alone at
+// 0.58 ms against 0.36 ms for whole lines).
 #include "dense_band_body.h"
 
 #ifndef WAVE_DEPTH
