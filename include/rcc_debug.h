@@ -25,8 +25,9 @@ extern "C" {
 
 /* ---- A/B switches between bit-identical variants (each returns the previous setting) -------------------------------- */
 /* threshold + corner pass: 0 = generic LDS tiles (any geometry), 1 = band kernel (k_dense_band.hip), 2 = strip march
- * (k_dense_fast.hip), 3 = band sweep + corner kernel on the active rows (k_dense_runs.hip); -1 = automatic (1 where the
- * geometry allows it, else 2, else 0) */
+ * (k_dense_fast.hip), 3 = band sweep + corner kernel on the active rows (k_dense_runs.hip), 4 = one independent wavefront
+ * per window where the binary image is kept as the compact map, the band kernel otherwise (k_dense_wave.hip);
+ * -1 = automatic (4 where the geometry allows it, else 2, else 0) */
 int rcc_set_dense_variant(rcc_handle* h, int variant);
 /* undistort + grey pass: 0 = gather (any geometry), 1 = LDS-staged tiles with the tabulated map, 2 = staged, map recomputed
  * per block; -1 = automatic */
