@@ -29,6 +29,9 @@
 #ifndef WAVE_DMA_NT
 #define WAVE_DMA_NT false
 #endif
+#ifndef WAVE_PRIO
+#define WAVE_PRIO 0           // s_setprio around the corner stages: independent waves have nobody to get ahead of (measured the same with 1)
+#endif
 
 template <int PRIO>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
@@ -181,9 +184,6 @@ hipError_t rcc_launch_dense_wave(rcc_handle* h, const uint8_t* d_grey, int nfram
   const int seg_tiles = (th + nseg - 1) / nseg;
   nseg = (th + seg_tiles - 1) / seg_tiles;
   const long long njobs = (long long)nbands * nseg * nwin * ((nframes + 8 * fchunk - 1) / (8 * fchunk)) * 8 * fchunk;
-#ifndef WAVE_PRIO
-#define WAVE_PRIO 0      // independent waves: nobody to get ahead of (measured the same with 1)
-#endif
   h->dense_kernel = "k_dense_wave<0>";
   hipLaunchKernelGGL((k_dense_wave<WAVE_PRIO>), dim3((unsigned)njobs), dim3(64), 0, s, d_grey, c.width, c.height, nbands, nwin, nseg, seg_tiles,
                      nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, rcc_dense_allow_skip(h), h->d_thr,
