@@ -7,6 +7,7 @@ from robot_camera_calibration_amd import abi, api, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 cfg = api.default_config(); abi.set_geometry(cfg, 1920, 1080); cfg.batch_capacity = B
 det = api.Detector(cfg)
+if len(sys.argv) > 2: det.set_ingest_variant(int(sys.argv[2]))
 frames = torch.randint(0, 255, (B, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
 grey = torch.empty((B, 1920 * 1080), dtype=torch.uint8, device="cuda:0")
 torch.cuda.synchronize()

@@ -217,6 +217,8 @@ def test_fisheye_ingest_bit_exact(torch_cuda, oracle):
     (abi.RCC_DIST_PLUMB_BOB, (-0.45, 0.25, 3e-3, -2e-3, -0.05), 1280, 720),     # strong: source boxes that do not fit the LDS stage take the gather path
     (abi.RCC_DIST_PLUMB_BOB, (0.35, 0.1, 0.0, 0.0, 0.0), 1280, 720),            # pincushion: the map leaves the image (border constant 0)
     (abi.RCC_DIST_FISHEYE, (-0.2, 0.05, -0.01, 0.002), 1280, 720),
+    (abi.RCC_DIST_PLUMB_BOB, (-0.45, 0.25, 3e-3, -2e-3, -0.05), 1152, 648),
+    (abi.RCC_DIST_FISHEYE, (-0.2, 0.05, -0.01, 0.002), 768, 432),
     (abi.RCC_DIST_NONE, (), 640, 480)])
 def test_ingest_adversarial_inputs(torch_cuda, oracle, model, coeffs, w, h):
     """undistort + grey on full-range noise and saturated colours, mild to strong distortion, all three forms of the pass
@@ -242,7 +244,7 @@ def test_ingest_adversarial_inputs(torch_cuda, oracle, model, coeffs, w, h):
         torch.cuda.synchronize()
         det.stage_ingest(frames, n, grey)
         outs.append(grey.cpu().numpy())
-    assert (outs[1] == outs[0]).all() and (outs[2] == outs[0]).all()
+    assert all((o == outs[0]).all() for o in outs[1:])
     for f in range(n):
         assert (outs[0][f].reshape(h, w) == oracle.ingest(cfg, host[f].reshape(-1))).all(), "grey differs from the oracle (image %d)" % f
     det.close()
