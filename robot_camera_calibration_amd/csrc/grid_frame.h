@@ -50,13 +50,28 @@ struct BinSrc {
   }
 };
 
+// The 16 ring samples are fetched in two rounds of independent loads -- all tile levels, then all grey values (always
+// in-image addresses; the grey value is simply not used where the level says "flat") -- instead of 16 dependent
+// level -> grey pairs one after the other: the ring test was 60 us of the 260 us this one-wave-per-frame kernel takes.
 __device__ __forceinline__ bool ring_ok(const BinSrc& b, int w, int h, int x, int y)
 {
   if (x < 5 || y < 5 || x >= w - 5 || y >= h - 5) return false;
   int v[16];
+  if (!b.thr) {
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    v[k] = b.at(x + c_ring16[k][0], y + c_ring16[k][1]);
+    for (int k = 0; k < 16; ++k) v[k] = b.bin[(size_t)(y + c_ring16[k][1]) * w + (x + c_ring16[k][0])];
+  } else {
+    int lv[16], g[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int xx = x + c_ring16[k][0], yy = y + c_ring16[k][1];
+      const int band = xx / RCC_BAND_W;
+      lv[k] = b.thr[((size_t)band * b.th + (yy >> 2)) * RCC_THR_PITCH + ((xx - band * RCC_BAND_W) >> 2)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g[k] = b.grey[(size_t)(y + c_ring16[k][1]) * w + (x + c_ring16[k][0])];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (lv[k] == 255) ? 127 : (g[k] > lv[k] ? 255 : 0);
   }
   int tr = 0;
   bool any127 = false;
@@ -82,9 +97,29 @@ struct grid_smem {
 
 #define LAB(i, j) sm.lab[((i) + GM) * GW + ((j) + GM)]
 
-// nearest point with used[k]==0 to (qx,qy); ties -> smaller index; returns -1 if none
+// nearest point with used[k]==0 to (qx,qy); ties -> smaller index; returns -1 if none.
+// SMALL (w^2 + h^2 < 2^24: every distance between two image points fits 24 bits): the key (distance << 8 | index) is one
+// dword and the wave-wide minimum a 32-bit reduction -- half the instructions of the 64-bit form, in a loop that runs ~200
+// times per frame on a single wave.  A query outside the image may be farther than 2^24 - 2 from every point; its distance
+// saturates there, and such a match is refused by the caller either way (8 * distance > step^2, step^2 < 2^24).
+template <bool SMALL>
 __device__ __forceinline__ int nearest_free(const grid_smem& sm, int n, int lane, long long qx, long long qy, long long* dist)
 {
+  if (SMALL) {
+    const int ix = (int)qx, iy = (int)qy;
+    unsigned best = ~0u;
+    for (int k = lane; k < n; k += 64) {
+      if (sm.used[k]) continue;
+      const int dx = sm.px[k] - ix, dy = sm.py[k] - iy;
+      const unsigned d = min((unsigned)(dx * dx) + (unsigned)(dy * dy), 0xFFFFFEu);
+      const unsigned key = (d << 8) | (unsigned)k;
+      best = key < best ? key : best;
+    }
+    best = wred::all_reduce32(best, [](unsigned a, unsigned b) { return a < b ? a : b; });
+    if (best == ~0u) return -1;
+    *dist = (long long)(best >> 8);
+    return (int)(best & 255u);
+  }
   unsigned long long best = ~0ull;
   for (int k = lane; k < n; k += 64) {
     if (sm.used[k]) continue;
@@ -172,6 +207,7 @@ __device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int
 
   // ---- a6 board indexing
   const int need = cols * rows;
+  const bool small = ((long long)w * w + (long long)h * h) < (1ll << 24) && w < 4096 && h < 4096;     // wave-uniform: see nearest_free
   bool found_board = false;
   if (target_kind == RCC_TARGET_CHECKERBOARD && nk >= need && nk <= RCC_MAX_KEPT && cols >= 2 && rows >= 2 &&
       cols <= GBOARD && rows <= GBOARD && need <= RCC_MAX_BOARD_CORNERS) {
@@ -205,7 +241,7 @@ __device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int
       __syncthreads();
       const long long sxp = sm.px[s], syp = sm.py[s];
       long long dd;
-      const int n1 = nearest_free(sm, nk, lane, sxp, syp, &dd);
+      const int n1 = small ? nearest_free<true>(sm, nk, lane, sxp, syp, &dd) : nearest_free<false>(sm, nk, lane, sxp, syp, &dd);
       if (n1 < 0) continue;
       const long long ux = sm.px[n1] - sxp, uy = sm.py[n1] - syp;
       const long long uu = ux * ux + uy * uy;
@@ -273,7 +309,7 @@ __device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int
             step2 = ex * ex + ey * ey;
           }
           long long dist = 0;
-          const int k = nearest_free(sm, nk, lane, predx, predy, &dist);
+          const int k = small ? nearest_free<true>(sm, nk, lane, predx, predy, &dist) : nearest_free<false>(sm, nk, lane, predx, predy, &dist);
           if (k < 0) continue;
           if (8 * dist > step2) continue;
           if (lane == 0) {
