@@ -48,15 +48,83 @@ def parse(argv=None):
     ap.add_argument("--sync-steps", action="store_true", help="time K synchronous detect() calls instead of the submit/collect stream of K batches")
     ap.add_argument("--pipeline", type=int, default=1, help="chunks of the detector's two-stream pipeline per step (1: single pass)")
     ap.add_argument("--fiducials", default="", help="BASELINE.json configs[4]-style run: GXxGY planar grid of square fiducials per frame, e.g. 6x4")
+    ap.add_argument("--no-pin", action="store_true", help="do not bind the rank's host threads to its GPU's NUMA node")
     ap.add_argument("--fisheye", action="store_true", help="BASELINE.json configs[3]-style run: fisheye model (use with --width 3840 --height 2160 --batch 256)")
     return ap.parse_args(argv)
 
 
-def launch_ranks(a):
-    """--gpus N > 1 without a launcher: start N ranks as a child torchrun (nothing in this process has touched a GPU)."""
-    import socket
+def visible_gpus_sysfs():
+    """GPUs this process could open, counted WITHOUT any HIP / torch call (the launcher parent must provably never touch
+    a GPU): KFD topology nodes that have SIMDs and whose render node exists in this container, capped by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  No KFD topology = no AMD GPU driver = 0."""
+    import glob
+    n = 0
+    for props in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        kv = {}
+        try:
+            for line in open(props):
+                parts = line.split()
+                if len(parts) == 2:
+                    kv[parts[0]] = parts[1]
+        except OSError:
+            continue
+        if int(kv.get("simd_count", "0")) > 0:
+            minor = kv.get("drm_render_minor")
+            if minor is None or int(minor) <= 0 or os.path.exists("/dev/dri/renderD%s" % minor):
+                n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def pin_to_gpu_numa(torch, local):
+    """Bind this rank's host threads to the CPUs of the NUMA node its GPU hangs off (the PCI device's local_cpulist),
+    intersected with the CPUs the process may use.  Silently does nothing where sysfs does not say (returns None)."""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        node = int(open(base + "/numa_node").read())
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0)
+        use = cpus & allowed
+        if node < 0 or not use:
+            return None
+        os.sched_setaffinity(0, use)
+        return {"pci": bdf, "numa_node": node, "cpus": len(use)}
+    except Exception:
+        return None
+
+
+def rank_report(dist, dev, world, dt_local, steps, found_local, gather, pinned):
+    """What makes a sub-linear N > 1 curve attributable (every rank contributes, rank 0 prints): each rank's own time per
+    step, the duration of its per-step collective, what it found, whether it was pinned.  Works on RCCL and gloo ranks."""
     import torch
-    n = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    mine = torch.tensor([1e3 * dt_local / max(steps, 1), gather.gather_ms() if gather.gather_ms() is not None else -1.0,
+                         float(found_local), 1.0 if pinned else 0.0, float(pinned["numa_node"]) if pinned else -1.0], dtype=torch.float64, device=dev)
+    allr = torch.zeros((world, mine.numel()), dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_gather_into_tensor(allr.view(-1), mine)
+    else:
+        allr[0] = mine
+    a = allr.cpu().tolist()
+    return {"per_rank_ms_per_step": [r[0] for r in a], "gather_ms_per_step": [(r[1] if r[1] >= 0 else None) for r in a],
+            "found_per_rank": [int(r[2]) for r in a], "ranks_pinned_to_numa": [bool(r[3]) for r in a], "numa_node_per_rank": [int(r[4]) for r in a],
+            "collective_world": (dist.get_world_size() if dist is not None else 1),
+            "collective_backend": (dist.get_backend() if dist is not None else "none")}
+
+
+def launch_ranks(a):
+    """--gpus N > 1 without a launcher: start N ranks as a child torchrun.  This parent never imports torch and never
+    makes a HIP call -- the devices are counted from sysfs (a rank that finds no device of its own fails by itself)."""
+    import socket
+    n = visible_gpus_sysfs()
     if n < a.gpus:
         sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: not running a smaller world in its place\n" % (a.gpus, n))
         return 2
@@ -84,6 +152,7 @@ def run_steps(det, frames, B, gather, steps, sync_steps):
     """The timed region's body: K steps of the whole path + the exchange of the records.  Works with any detector that
     has detect / submit / collect (tests/test_dist_gloo.py drives it with a stand-in on CPU ranks)."""
     found = 0
+    run_steps.local_found = 0        # records THIS rank produced in its last step (found: records visible after the exchange)
     run_steps.dense_ms = []          # in-step duration of the threshold + corner launch of every streamed step (HIP events)
     # ranks that exchange device-packed tables keep the detector on the stream the collective is ordered with, and count
     # the gathered records (a host synchronisation) only after the last step
@@ -92,6 +161,7 @@ def run_steps(det, frames, B, gather, steps, sync_steps):
         for k in range(steps):
             getattr(gather, "before_submit", lambda s: None)(0)
             dets, _ = det.detect(frames, B, want_corners=False, **kw)
+            run_steps.local_found = len(dets)
             found = gather.exchange(dets, 0, k == steps - 1)
     else:
         # the streaming form of the same K steps (rcc_detect_batch_submit / _collect): batch k+1 is launched before
@@ -104,6 +174,7 @@ def run_steps(det, frames, B, gather, steps, sync_steps):
             if k + 1 < steps:
                 before(slot_of_next); det.submit(frames, B, **kw); slot_of_next ^= 1
             dets, _ = det.collect()
+            run_steps.local_found = len(dets)
             if hasattr(det, "last_timings"):
                 run_steps.dense_ms.append(det.last_timings()["dense"])
             found = gather.exchange(dets, getattr(det, "last_slot", 0), k == steps - 1)
@@ -148,8 +219,12 @@ def main():
     import numpy as np
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if local >= torch.cuda.device_count():
+        sys.stderr.write("bench.py: rank %d wants device %d, %d visible\n" % (rank, local, torch.cuda.device_count()))
+        return 2
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    pinned = pin_to_gpu_numa(torch, local) if not a.no_pin else None
     dist = None
     if "WORLD_SIZE" in os.environ:          # launched by torchrun: the distributed path, whatever the world size (a world of
         import torch.distributed as dist    # one still runs the RCCL calls: init, barrier, all_gather of the record tables)
@@ -206,13 +281,17 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    gather.reset_timing()
     t0 = time.perf_counter()
     found = run_steps(det, frames, B, gather, a.steps, a.sync_steps)
     dense_in_step = list(run_steps.dense_ms)
+    found_local = run_steps.local_found
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0          # this rank's own K steps, before it waits for the others
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    ranks = rank_report(dist, dev, world, dt_local, a.steps, found_local, gather, pinned)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -253,6 +332,7 @@ def main():
                        "target": ("%dx%d square fiducials of 0.10 m per frame (build family36b), 4-point PnP per tag" % fid) if fid else "8x6 inner-corner checkerboard, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
                        "parallelism": "frame-sharded, 1 process per GPU, 1 all_gather of pose records (19 doubles per target slot, packed on the device) per step"},
             "targets_found_in_last_step": int(found), "targets_expected_per_step": int(world * B * tpf), "stage_ms_single_pass": timings, "pipeline_chunks": a.pipeline, "step_form": "sync detect()" if a.sync_steps else "submit/collect, one batch ahead", "value_with_sync_steps": sync_fps,
+            "ranks": ranks,
         }
 
     # ---- roofline of the threshold+corner pass (the pass BASELINE.json's north_star names) AS THE STEP RUNS IT, and of

@@ -225,9 +225,12 @@ int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet);
  *   [11..18] the four corners bl, br, tr, tl as x,y -- all four, as the consumer reads them (corner_detections.cpp:51-56)
  * d_table0 serves rcc_detect_batch and the submissions in result slot 0, d_table1 those in slot 1 (NULL: d_table0 for
  * both -- then a table must be consumed before the next submission).  A submission's table is complete when its
- * rcc_detect_batch_collect returns.  NULL, NULL switches the tables off.  include/rcc_dist.h gathers such tables over RCCL. */
+ * rcc_detect_batch_collect returns.  NULL, NULL switches the tables off.  include/rcc_dist.h gathers such tables over RCCL.
+ * capacity_slots = slots each table holds (>= 1 when a table is given): a batch whose rcc_record_slots(nframes) exceeds it
+ * is refused with RCC_ERR_CAPACITY before anything is launched, and a SHORTER batch (a ragged last one) leaves the slots
+ * [rcc_record_slots(nframes), capacity_slots) all zeros -- a gather of the whole table never sees a previous batch's records. */
 #define RCC_REC_DOUBLES 19
-int rcc_set_record_tables(rcc_handle* h, double* d_table0, double* d_table1, int32_t frame_offset);
+int rcc_set_record_tables(rcc_handle* h, double* d_table0, double* d_table1, int32_t capacity_slots, int32_t frame_offset);
 int rcc_record_slots(const rcc_handle* h, int32_t nframes);
 
 /* a1+a2: ingest = BGR->grey (+ undistort when cfg.undistort).  src/dst device pointers;

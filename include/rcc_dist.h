@@ -34,6 +34,8 @@ int  rcc_dist_world(const rcc_dist* d);
  * (device), rank r's table at offset r * nslots.  Asynchronous on `stream` (hipStream_t; NULL: the default stream). */
 int  rcc_dist_allgather_records(rcc_dist* d, const double* d_table, int32_t nslots, double* d_all, void* stream);
 const char* rcc_dist_last_error(const rcc_dist* d);
+/* text of the failure of this thread's last rcc_dist_unique_id / rcc_dist_create (they have no handle to carry it); "" after a success */
+const char* rcc_dist_last_create_error(void);
 
 #ifdef __cplusplus
 }

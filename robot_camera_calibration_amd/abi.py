@@ -124,13 +124,18 @@ RCC_MAX_KEPT_FIDUCIAL = 2048
 _FAMILY_CACHE = {}
 
 
+def family_path(name="family36b"):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", name + ".txt")
+
+
 def load_family(name="family36b"):
     """The build-generated 36-bit family (data/family36b.txt, made by data/make_family.py): numpy
     uint64 array.  Keep the array alive while a config points at it."""
     import os
     import numpy as np
     if name not in _FAMILY_CACHE:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", name + ".txt")
+        path = family_path(name)
         _FAMILY_CACHE[name] = np.array([int(l, 16) for l in open(path) if l.strip() and not l.startswith("#")], dtype=np.uint64)
     return _FAMILY_CACHE[name]
 

@@ -104,7 +104,7 @@ def load_library():
     L.rcc_last_dense_kernel.restype = C.c_char_p
     L.rcc_set_pnp_mfma.argtypes = [P, C.c_int]
     L.rcc_set_pnp_mfma.restype = C.c_int
-    L.rcc_set_record_tables.argtypes = [P, P, P, I]
+    L.rcc_set_record_tables.argtypes = [P, P, P, I, I]
     L.rcc_set_record_tables.restype = C.c_int
     L.rcc_record_slots.argtypes = [P, I]
     L.rcc_record_slots.restype = C.c_int
@@ -135,7 +135,7 @@ DEBUG_EXPORTED_SYMBOLS = (
 )
 # include/rcc_dist.h (librcc_dist.so: the RCCL all-gather of the record tables for non-Python hosts)
 DIST_EXPORTED_SYMBOLS = ("rcc_dist_unique_id", "rcc_dist_create", "rcc_dist_destroy", "rcc_dist_rank", "rcc_dist_world",
-                         "rcc_dist_allgather_records", "rcc_dist_last_error")
+                         "rcc_dist_allgather_records", "rcc_dist_last_error", "rcc_dist_last_create_error")
 
 
 def dist_library_path():
@@ -339,12 +339,17 @@ class Detector:
         """slots of the record table of an nframes batch (rcc_set_record_tables)"""
         return int(self._L.rcc_record_slots(self._h, int(nframes)))
 
-    def set_record_tables(self, t0, t1=None, frame_offset=0):
-        """Device tables (record_slots(n) x abi.RCC_REC_DOUBLES float64 each) that every following detect() / submit()
-        also fills on the device: t0 for detect() and submissions in result slot 0, t1 for those in slot 1.  The
-        tensors must stay alive while they are registered; (None, None) switches the tables off."""
+    def set_record_tables(self, t0, t1=None, frame_offset=0, capacity_slots=None):
+        """Device tables (capacity_slots x abi.RCC_REC_DOUBLES float64 each; default: t0's first dimension) that every
+        following detect() / submit() also fills on the device: t0 for detect() and submissions in result slot 0, t1 for
+        those in slot 1.  A batch that needs more slots is refused (RCC_ERR_CAPACITY), a shorter one leaves the rest of the
+        table zero.  The tensors must stay alive while they are registered; (None, None) switches the tables off."""
         self._rec_tables = (t0, t1)
-        self._chk(self._L.rcc_set_record_tables(self._h, _ptr(t0), _ptr(t1), int(frame_offset)), "rcc_set_record_tables")
+        if capacity_slots is None:
+            capacity_slots = 0 if t0 is None else int(t0.shape[0])
+            if t1 is not None:
+                capacity_slots = min(capacity_slots, int(t1.shape[0]))
+        self._chk(self._L.rcc_set_record_tables(self._h, _ptr(t0), _ptr(t1), int(capacity_slots), int(frame_offset)), "rcc_set_record_tables")
 
     def set_dense_variant(self, v):
         return self._L.rcc_set_dense_variant(self._h, int(v))

@@ -221,7 +221,14 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
         (void)hipGetLastError();
       } else {
         hipLaunchKernelGGL(k_ingest_map, dim3(tiles), dim3(256), 0, s, w, ht, cam, ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
-        (void)hipStreamSynchronize(s);      // once per handle: later launches may come on other streams
+        hipError_t em = hipGetLastError();
+        if (em == hipSuccess) em = hipStreamSynchronize(s);      // once per handle: later launches may come on other streams
+        if (em != hipSuccess) {
+          // tables that may not have been written must never be read: drop them, the kernel recomputes the map per block
+          (void)hipFree(h->d_map); (void)hipFree(h->d_tilebox);
+          h->d_map = nullptr; h->d_tilebox = nullptr; h->map_failed = 1;
+          return em;
+        }
       }
     }
     const int2* mp = h->ingest_table ? (const int2*)h->d_map : nullptr;

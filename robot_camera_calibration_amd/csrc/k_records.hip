@@ -7,13 +7,15 @@
 #include "rcc_internal.h"
 
 __global__ __launch_bounds__(256) void k_pack_records(const rcc_detection* __restrict__ det, const int32_t* __restrict__ ndet, int nframes,
-                                                      int tpf, int det_stride, int frame_offset, double* __restrict__ table)
+                                                      int tpf, int det_stride, int frame_offset, int capacity, double* __restrict__ table)
 {
   const int slot = blockIdx.x * 256 + threadIdx.x;
-  if (slot >= nframes * tpf) return;
+  if (slot >= capacity) return;
   const int f = slot / tpf, q = slot - f * tpf;
   double* o = table + (size_t)slot * RCC_REC_DOUBLES;
-  const int n = min(ndet[f], tpf);
+  // slots beyond this batch (a batch shorter than the table: the ragged last one) are cleared, so that a gather of the
+  // whole table never hands on the previous batch's records
+  const int n = f < nframes ? min(ndet[f], tpf) : 0;
   if (q >= n) {
 #pragma unroll
     for (int i = 0; i < RCC_REC_DOUBLES; ++i) o[i] = 0.0;
@@ -32,8 +34,8 @@ hipError_t rcc_launch_pack_records(rcc_handle* h, int nframes, int frame_offset,
 {
   const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
   const int tpf = fid ? h->cfg.max_targets : 1;
-  const int n = nframes * tpf;
+  const int n = h->rec_capacity;            // >= nframes * tpf: checked where the batch is accepted
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_pack_records, dim3((n + 255) / 256), dim3(256), 0, s, h->d_det, h->d_ndet, nframes, tpf, tpf, frame_offset, d_table);
+  hipLaunchKernelGGL(k_pack_records, dim3((n + 255) / 256), dim3(256), 0, s, h->d_det, h->d_ndet, nframes, tpf, tpf, frame_offset, n, d_table);
   return hipGetLastError();
 }

@@ -318,6 +318,8 @@ int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n)
   return k;
 }
 
+static bool records_fit(const rcc_handle* h, int nframes);
+
 // ---- stages ------------------------------------------------------------------------------------
 int rcc_stage_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey, void* stream)
 {
@@ -471,7 +473,7 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
 {
   if (!h || (!frames && nframes > 0) || nframes < 0) return RCC_ERR_ARG;
   if (frames_mem != RCC_MEM_HOST && frames_mem != RCC_MEM_DEVICE) return RCC_ERR_ARG;
-  if (nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
+  if (nframes > h->cfg.batch_capacity || !records_fit(h, nframes)) return RCC_ERR_CAPACITY;
   if (ndet) *ndet = 0;
   if (nframes == 0) return RCC_OK;
   if (h->sub_head != h->sub_tail) return RCC_ERR_STATE;              // submissions outstanding: collect them first
@@ -508,6 +510,9 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
       const int f0 = (int)((long long)nframes * c / nchunks), f1 = (int)((long long)nframes * (c + 1) / nchunks);
       rcc_handle v = handle_view(h, f0);
       v.want_thr = h->keep_bin ? 0 : 1;
+      // the two-kernel form (variant 3) keeps its flat masks in ONE per-handle buffer indexed from frame 0: two chunks in
+      // flight on the two streams would share its words, so a chunked batch runs the fused band kernel instead (bit-identical)
+      if (v.dense_variant == 3) v.dense_variant = 1;
       hipStream_t cs = h->pstream[c & 1];
       hipError_t e = rcc_launch_ingest(&v, d_frames + (size_t)f0 * h->cfg.frame_bytes, f1 - f0, v.d_grey, cs);
       h->d_map = v.d_map; h->d_tilebox = v.d_tilebox; h->map_failed = v.map_failed;     // tables built by the first launch belong to the handle
@@ -549,7 +554,7 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
 {
   if (!h || !frames || nframes < 1) return RCC_ERR_ARG;
   if (frames_mem != RCC_MEM_HOST && frames_mem != RCC_MEM_DEVICE) return RCC_ERR_ARG;
-  if (nframes > h->cfg.batch_capacity) return RCC_ERR_CAPACITY;
+  if (nframes > h->cfg.batch_capacity || !records_fit(h, nframes)) return RCC_ERR_CAPACITY;
   if (h->sub_head - h->sub_tail >= 2) return RCC_ERR_STATE;          // both result slots are in flight
   HIPCHK(h, hipSetDevice(h->device));
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
@@ -626,13 +631,19 @@ int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet)
 }
 
 // record tables for the exchange between ranks (k_records.hip)
-int rcc_set_record_tables(rcc_handle* h, double* d_table0, double* d_table1, int32_t frame_offset)
+int rcc_set_record_tables(rcc_handle* h, double* d_table0, double* d_table1, int32_t capacity_slots, int32_t frame_offset)
 {
-  if (!h || (d_table1 && !d_table0)) return RCC_ERR_ARG;
+  if (!h || (d_table1 && !d_table0) || (d_table0 && capacity_slots < 1)) return RCC_ERR_ARG;
   if (h->sub_head != h->sub_tail) return RCC_ERR_STATE;
   h->rec_table[0] = d_table0; h->rec_table[1] = d_table1 ? d_table1 : d_table0;
+  h->rec_capacity = d_table0 ? capacity_slots : 0;
   h->rec_offset = frame_offset;
   return RCC_OK;
+}
+// a batch whose records do not fit the caller's tables is refused before anything is launched
+static bool records_fit(const rcc_handle* h, int nframes)
+{
+  return !h->rec_table[0] || rcc_record_slots(h, nframes) <= h->rec_capacity;
 }
 int rcc_record_slots(const rcc_handle* h, int32_t nframes)
 {

@@ -16,13 +16,20 @@ struct rcc_dist {
   char err[256];
 };
 
+// why the last rcc_dist_unique_id / rcc_dist_create of this thread failed: there is no handle to carry the text yet
+static thread_local char g_create_err[256] = "";
+
 extern "C" {
+
+const char* rcc_dist_last_create_error(void) { return g_create_err; }
 
 int rcc_dist_unique_id(void* id)
 {
   if (!id) return RCC_ERR_ARG;
+  g_create_err[0] = 0;
   ncclUniqueId u;
-  if (ncclGetUniqueId(&u) != ncclSuccess) return RCC_ERR_DEVICE;
+  ncclResult_t r = ncclGetUniqueId(&u);
+  if (r != ncclSuccess) { snprintf(g_create_err, sizeof(g_create_err), "ncclGetUniqueId: %s", ncclGetErrorString(r)); return RCC_ERR_DEVICE; }
   memset(id, 0, RCC_DIST_ID_BYTES);
   memcpy(id, &u, sizeof(u));
   return RCC_OK;
@@ -33,9 +40,15 @@ int rcc_dist_create(int32_t rank, int32_t world, const void* id, int32_t device,
   if (!out) return RCC_ERR_ARG;
   *out = nullptr;
   if (!id || world < 1 || rank < 0 || rank >= world || device < 0) return RCC_ERR_ARG;
+  g_create_err[0] = 0;
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) return RCC_ERR_DEVICE;
-  if (hipSetDevice(device) != hipSuccess) return RCC_ERR_DEVICE;
+  hipError_t he = hipGetDeviceCount(&ndev);
+  if (he != hipSuccess || device >= ndev) {
+    snprintf(g_create_err, sizeof(g_create_err), "device %d of %d visible (%s)", device, ndev, hipGetErrorString(he));
+    return RCC_ERR_DEVICE;
+  }
+  he = hipSetDevice(device);
+  if (he != hipSuccess) { snprintf(g_create_err, sizeof(g_create_err), "hipSetDevice(%d): %s", device, hipGetErrorString(he)); return RCC_ERR_DEVICE; }
   rcc_dist* d = new (std::nothrow) rcc_dist();
   if (!d) return RCC_ERR_NOMEM;
   memset(d, 0, sizeof(*d));
@@ -43,7 +56,11 @@ int rcc_dist_create(int32_t rank, int32_t world, const void* id, int32_t device,
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   ncclResult_t r = ncclCommInitRank(&d->comm, world, u, rank);
-  if (r != ncclSuccess) { delete d; return RCC_ERR_DEVICE; }
+  if (r != ncclSuccess) {
+    snprintf(g_create_err, sizeof(g_create_err), "ncclCommInitRank(rank %d of %d): %s", rank, world, ncclGetErrorString(r));
+    delete d;
+    return RCC_ERR_DEVICE;
+  }
   *out = d;
   return RCC_OK;
 }

@@ -64,6 +64,7 @@ struct rcc_handle {
   size_t flat_bytes;
   double* rec_table[2];     // rcc_set_record_tables: the caller's device tables, one per result slot (NULL: none)
   int rec_offset;           // global index of the batch's first frame in those tables
+  int rec_capacity;         // slots each of those tables holds (the packer zeroes the slots a shorter batch leaves)
   const char* dense_kernel; // name(s) of the kernel(s) the last threshold + corner launch used, as rocprofv3 prints them
   void* d_map;              // staged ingest: Q5 map of the handle's camera (w * h int2) and the tiles' source boxes (int4 each),
   void* d_tilebox;          //   tabulated at the first staged launch (k_ingest_map)

@@ -78,6 +78,8 @@ class PoseGather:
         # the end of the last gather that read table i
         self.side = torch.cuda.Stream(device) if on_gpu else None
         self.done = [None, None]
+        # duration of every collective since reset_timing(): event pairs on the side stream (GPU ranks), wall clock (CPU ranks)
+        self._gather_ev, self._gather_s = [], []
 
     def attach(self, detector, frame_offset=0):
         """GPU ranks: let the detector pack its records into this gather's tables on the device"""
@@ -99,10 +101,14 @@ class PoseGather:
                 return self.run_table(t) if count else (self.dist.all_gather_into_tensor(self.recv, t), -1)[1]
             # the table is complete (the caller has collected the batch), so the side stream has nothing to wait for
             with torch.cuda.stream(self.side):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
                 self.dist.all_gather_into_tensor(self.recv, t)
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=True)
                 ev.record(self.side)
+                self._gather_ev.append((e0, ev))
                 self.done[i] = ev
+                self.last_done = ev
                 n = int((self.recv[:, 0] > 0.5).sum().item()) if count else -1
             return n
         return self.run(dets, self.frame_offset)
@@ -127,8 +133,22 @@ class PoseGather:
         records visible to this rank"""
         if self.dist is None:
             return int((table[:, 0] > 0.5).sum().item())
+        import time
+        t0 = time.perf_counter()
         self.dist.all_gather_into_tensor(self.recv, table)
-        return int((self.recv[:, 0] > 0.5).sum().item())
+        n = int((self.recv[:, 0] > 0.5).sum().item())      # also the synchronisation that ends the collective on a GPU rank
+        self._gather_s.append(time.perf_counter() - t0)
+        return n
+
+    def reset_timing(self):
+        self._gather_ev, self._gather_s = [], []
+
+    def gather_ms(self):
+        """mean duration of the collectives since reset_timing() in ms (None if there were none): HIP events around the
+        all_gather on the side stream for GPU ranks (call after a synchronisation), wall clock around the blocking call
+        for CPU ranks and the synchronous GPU form"""
+        ms = [a.elapsed_time(b) for a, b in self._gather_ev] + [1e3 * s for s in self._gather_s]
+        return (sum(ms) / len(ms)) if ms else None
 
     def run(self, dets, frame_offset=0):
         """host records -> table -> exchange (CPU ranks; GPU ranks use attach() + run_table())"""
@@ -137,4 +157,14 @@ class PoseGather:
         return self.run_table(t)
 
     def gathered(self):
-        return self.recv if self.recv is not None else self.tables[0]
+        """The gathered records (world x nslots x REC).  GPU ranks: the collective ran on the side stream, so torch's
+        current stream is first made to wait for the last gather (a device-side wait) -- a reader on that stream, or a
+        .cpu() issued from it, then sees the complete buffer.  There is ONE receive buffer: it holds a batch's records
+        until the next exchange() overwrites it, so consume (or copy) it before exchanging the next batch."""
+        if self.recv is None:
+            return self.tables[0]
+        if self.side is not None:
+            last = getattr(self, "last_done", None)
+            if last is not None:
+                torch.cuda.current_stream(self.device).wait_event(last)
+        return self.recv

@@ -6,9 +6,34 @@
 // pixel_corners_y[0..3] (real_preprocessing/src/corner_detections.cpp:43-54) -- plus the upstream pose
 // field (never read by the reference).  Corner order bl, br, tr, tl (camera_pose.cpp:123-126).
 #pragma once
+#include <cerrno>
 #include <cstdint>
 #include <cstdlib>
+#include <istream>
+#include <string>
+#include <vector>
 #include "rcc.h"
+
+// The node's `family_file`: one code word per line, hexadecimal (with or without 0x), 36-bit row-major payload, MSB
+// first (rcc_config.family_codes; data/family_from_apriltag.py writes this format from an apriltag family description).
+// Blank lines and lines starting with '#' are skipped.  Nothing here throws: a malformed line (not hexadecimal, trailing
+// garbage, more than 36 bits) is counted in *bad_lines and skipped, so a typo in the file cannot terminate the node at start-up.
+inline void rcc_parse_family(std::istream& in, std::vector<uint64_t>& codes, int* bad_lines)
+{
+  int bad = 0;
+  for (std::string line; std::getline(in, line);) {
+    size_t b = line.find_first_not_of(" \t\r");
+    if (b == std::string::npos || line[b] == '#') continue;
+    const char* p = line.c_str() + b;
+    char* end = nullptr;
+    errno = 0;
+    const unsigned long long v = std::strtoull(p, &end, 16);
+    bool ok = end != p && errno == 0 && (v >> 36) == 0 && *p != '-' && *p != '+';
+    for (const char* q = end; ok && *q; ++q) ok = (*q == ' ' || *q == '\t' || *q == '\r');
+    if (ok) codes.push_back((uint64_t)v); else ++bad;
+  }
+  if (bad_lines) *bad_lines = bad;
+}
 
 template <class ArrayMsg, class DetMsg, class Header>
 inline void rcc_fill_tag_detections(const rcc_detection* det, int n, const Header& header, ArrayMsg& out)

@@ -39,8 +39,9 @@ class RccDetectorNode {
     pnh.param<int>("max_targets", max_targets_, 64);
     pnh.param<int>("max_hamming", max_hamming_, 2);
     std::ifstream in(family_file.c_str());
-    for (std::string line; std::getline(in, line);)
-      if (!line.empty() && line[0] != '#') family_.push_back(std::stoull(line, nullptr, 16));
+    int bad_lines = 0;
+    rcc_parse_family(in, family_, &bad_lines);        // never throws: malformed lines are skipped and counted
+    if (bad_lines) ROS_ERROR("rcc_detector: %d malformed line(s) skipped in family file '%s'", bad_lines, family_file.c_str());
     if (family_.empty()) ROS_ERROR("rcc_detector: no tag family loaded from '%s'", family_file.c_str());
     det_.resize(max_targets_ > 0 ? max_targets_ : 1);
     pub_ = nh_.advertise<apriltag_ros::AprilTagDetectionArray>("tag_detections", 1);

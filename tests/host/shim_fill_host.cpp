@@ -3,6 +3,7 @@
 // consumer reads (real_preprocessing/src/corner_detections.cpp:43-54).  No ROS involved.
 #include <vector>
 #include <cstring>
+#include <sstream>
 #include "../../include/rcc.h"
 #include "../../robot_camera_calibration_amd/host/tag_detections_fill.h"
 
@@ -44,4 +45,14 @@ extern "C" int shimfill_roundtrip(const rcc_detection* det, int n, unsigned seq,
 extern "C" void shimfill_draw(unsigned char* img, int width, int height, int step, int channels, const rcc_detection* det, int n)
 {
   rcc_draw_detections(img, width, height, step, channels, det, n);
+}
+
+// the node's family_file parser: returns the number of codes (at most cap are copied out), *bad = malformed lines skipped
+extern "C" int shimfill_parse_family(const char* text, unsigned long long* out, int cap, int* bad)
+{
+  std::istringstream in(text);
+  std::vector<uint64_t> codes;
+  rcc_parse_family(in, codes, bad);
+  for (size_t i = 0; i < codes.size() && (int)i < cap; ++i) out[i] = codes[i];
+  return (int)codes.size();
 }

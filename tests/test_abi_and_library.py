@@ -83,6 +83,11 @@ def test_dist_library_exports_every_declared_symbol(built):
     assert L.rcc_dist_create(2, 2, ident, 0, C.byref(h)) == abi.RCC_ERR_ARG          # rank >= world
     assert L.rcc_dist_create(0, 1, None, 0, C.byref(h)) == abi.RCC_ERR_ARG
     assert L.rcc_dist_unique_id(None) == abi.RCC_ERR_ARG
+    # a create that fails on the device side (no such device: this works with and without a GPU) leaves its reason where
+    # the caller can read it -- there is no handle to ask
+    L.rcc_dist_last_create_error.restype = C.c_char_p
+    assert L.rcc_dist_create(0, 1, ident, 4096, C.byref(h)) == abi.RCC_ERR_DEVICE and not h.value
+    assert b"device 4096" in L.rcc_dist_last_create_error()
     assert re.search(r"#define\s+RCC_REC_DOUBLES\s+19", open(os.path.join(ROOT, "include", "rcc.h")).read()) and abi.RCC_REC_DOUBLES == 19
 
 

@@ -142,12 +142,18 @@ def _bench_worker(rank, world, port, nframes, q):
     g = rdist.PoseGather(nframes, torch.device("cpu"), world, dist, rank)
     g.frame_offset = rank * nframes
     det = _StandInDetector(rank, nframes)
+    import time
+    g.reset_timing()
+    t0 = time.perf_counter()
     found_stream = bench.run_steps(det, None, nframes, g, 3, False)
+    dt = time.perf_counter() - t0
     tab = g.gathered().numpy().copy()
+    # the fields that make an N > 1 line attributable: every rank contributes, every rank gets all of them
+    rep = bench.rank_report(dist, torch.device("cpu"), world, dt, 3, bench.run_steps.local_found, g, {"numa_node": rank, "pci": "x", "cpus": 1} if rank == 1 else None)
     found_sync = bench.run_steps(det, None, nframes, g, 2, True)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, found_stream, found_sync, tab, det.calls))
+    q.put((rank, found_stream, found_sync, tab, det.calls, rep))
 
 
 def test_bench_step_loop_world2():
@@ -162,8 +168,13 @@ def test_bench_step_loop_world2():
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
     for p in ps: p.join(30)
     exp = sum(len(_fake_dets(r, nframes)) for r in range(world))
-    for rank, fs, fy, tab, calls in res:
+    for rank, fs, fy, tab, calls, rep in res:
         assert fs == exp and fy == exp
+        assert rep["collective_world"] == world and rep["collective_backend"] == "gloo"
+        assert rep["found_per_rank"] == [len(_fake_dets(r, nframes)) for r in range(world)] and sum(rep["found_per_rank"]) == exp
+        assert len(rep["per_rank_ms_per_step"]) == world and all(v > 0 for v in rep["per_rank_ms_per_step"])
+        assert len(rep["gather_ms_per_step"]) == world and all(v is not None and v > 0 for v in rep["gather_ms_per_step"])   # 3 collectives timed per rank
+        assert rep["ranks_pinned_to_numa"] == [False, True] and rep["numa_node_per_rank"] == [-1, 1]
         assert calls[:7] == ["submit", "submit", "collect", "submit", "collect", "collect", "detect"]
         for r in range(world):
             _check_block(tab[r * nframes:(r + 1) * nframes], _fake_dets(r, nframes), nframes, 1, r * nframes)
@@ -181,6 +192,11 @@ def test_bench_refuses_a_smaller_world():
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "n_gpus" not in r.stdout
     assert "--gpus 2" in r.stderr
+    # the launcher parent counts devices from sysfs: it must get to its verdict without importing torch (no HIP call)
+    code = ("import sys; sys.path.insert(0, %r); sys.argv = ['bench.py', '--gpus', '2']; import bench; rc = bench.main(); "
+            "assert 'torch' not in sys.modules, 'the launcher parent imported torch'; sys.exit(rc)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "AssertionError" not in r.stderr, r.stderr
     # launched as one rank of a world that does not match --gpus: an error as well
     env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "1", "0", "0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)

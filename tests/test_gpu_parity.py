@@ -623,6 +623,25 @@ def test_config4_fisheye_4k(torch_cuda, oracle):
     print("max diffs", mx)
 
 
+def test_config2_headline_full_path_1080p(torch_cuda, oracle):
+    """BASELINE.json configs[1] inside pytest: 64 rendered 1920x1080 BGR8 checkerboard frames, plumb-bob, undistort on
+    -- the bench workload's first 64 frames (same seed, same poses) -- through rcc_detect_batch and the oracle: every
+    stage of every frame (grey, threshold map, candidate / suppressed / validated lists, corner indices bit-exact;
+    sub-pixel corners, rvec, tvec within 1e-4).  A frame the detector rejects must be rejected by the oracle too: an
+    empty detection array is silently skipped by the consumer (corner_detections.cpp:43-56)."""
+    n = 64
+    cfg = _make(w=1920, h=1080, B=n)
+    det = api.Detector(cfg)
+    sp = abi.default_synth_params()
+    poses = synth.sample_poses(n, cfg)
+    frames = torch_cuda.empty((n, cfg.frame_bytes), dtype=torch_cuda.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    det.close()
+    mx, found = _check_batch(torch_cuda, oracle, cfg, frames, n, expect_found=False)
+    print("1920x1080 x %d: board found in %d, max diffs %s" % (n, found, mx))
+    assert found >= n - 2
+
+
 def test_record_tables_packed_on_device(torch_cuda):
     """rcc_set_record_tables: the table the ranks exchange is packed on the device by the detector (csrc/k_records.hip);
     it must equal the host form of the same layout (dist.pack) built from the records detect() returns -- every field,
@@ -650,6 +669,25 @@ def test_record_tables_packed_on_device(torch_cuda):
         d, _ = det.collect()
         assert det.last_slot == k
         assert np.array_equal((t0, t1)[det.last_slot].cpu().numpy(), rdist.pack(d, n, 1, 1000))
+    # a full batch followed by a SHORTER one (the ragged last batch of a stream): the slots the short batch does not
+    # cover are all zeros -- a gather of the whole table must never hand on the previous batch's records
+    det.detect(frames, n)
+    short = 4
+    ds, _ = det.detect(frames[:short].contiguous(), short)
+    got = t0.cpu().numpy()
+    assert np.array_equal(got[:short], rdist.pack(ds, short, 1, 1000)) and (got[short:] == 0.0).all()
+    det.submit(frames, n); det.collect()
+    det.submit(frames[:short].contiguous(), short); det.collect()
+    got = (t0, t1)[det.last_slot].cpu().numpy()
+    assert np.array_equal(got[:short], rdist.pack(ds, short, 1, 1000)) and (got[short:] == 0.0).all()
+    # a batch that needs more slots than the registered tables hold is refused before anything is launched
+    det.set_record_tables(t0, t1, frame_offset=0, capacity_slots=short)
+    with pytest.raises(api.RccError) as e:
+        det.detect(frames, n)
+    assert e.value.status == abi.RCC_ERR_CAPACITY
+    with pytest.raises(api.RccError) as e:
+        det.submit(frames, n)
+    assert e.value.status == abi.RCC_ERR_CAPACITY
     det.set_record_tables(None, None)
     t0.fill_(-7.0); torch.cuda.synchronize()
     det.detect(frames, n)
