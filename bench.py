@@ -202,6 +202,176 @@ def host_cpus():
     return n, quota, model
 
 
+def _frame_cmp(cfg, fid, f, g_dets, g_fc, n, od, ofc, acc):
+    """one frame, GPU records against the oracle's: index / id / status mismatches are counted, float differences maxed"""
+    import numpy as np
+    if fid:
+        if n != len(g_dets):
+            acc["mism"] += 1
+            return
+        for q in range(n):
+            if g_dets[q].id != od[q].id:
+                acc["mism"] += 1
+                continue
+            acc["corner"] = max(acc["corner"], float(np.abs(np.array(g_dets[q].corners) - np.array([[od[q].corners[c][0], od[q].corners[c][1]] for c in range(4)])).max()))
+            acc["rvec"] = max(acc["rvec"], float(np.abs(np.array(list(g_dets[q].rvec)) - np.array(list(od[q].rvec))).max()))
+            acc["tvec"] = max(acc["tvec"], float(np.abs(np.array(list(g_dets[q].tvec)) - np.array(list(od[q].tvec))).max()))
+        return
+    nc = cfg.board_cols * cfg.board_rows
+    if (ofc.ncorners != g_fc.ncorners) or (ofc.status != g_fc.status) or (ofc.ncand != g_fc.ncand) or (ofc.nkept != g_fc.nkept) or (n != len(g_dets)):
+        acc["mism"] += 1
+        return
+    if n:
+        gp = np.array([[g_fc.px[k][0], g_fc.px[k][1]] for k in range(nc)])
+        op = np.array([[ofc.px[k][0], ofc.px[k][1]] for k in range(nc)])
+        acc["mism"] += int((gp != op).any())
+        gx = np.array([[g_fc.xy[k][0], g_fc.xy[k][1]] for k in range(nc)])
+        ox = np.array([[ofc.xy[k][0], ofc.xy[k][1]] for k in range(nc)])
+        acc["corner"] = max(acc["corner"], float(np.abs(gx - ox).max()))
+        acc["rvec"] = max(acc["rvec"], float(np.abs(np.array(list(g_dets[0].rvec)) - np.array(list(od.rvec))).max()))
+        acc["tvec"] = max(acc["tvec"], float(np.abs(np.array(list(g_dets[0].tvec)) - np.array(list(od.tvec))).max()))
+
+
+def cpu_and_accuracy_legs(a, out, det, cfg, frames, poses, B, fid, tpf):
+    """rank 0, N = 1, after the timed region.  (1) cpu_baseline: the oracle (kind "port") timed on the host's cores on a
+    bounded sample.  (2) accuracy_vs_oracle: every stage-level figure on the first frames AND on every frame the detector
+    did not answer completely.  (3) a status pass of the oracle over ALL frames of the batch: a frame the detector rejects
+    must be one the oracle rejects too -- the consumer silently skips an empty array (corner_detections.cpp:43-56), so a
+    wrongly empty frame would be lost without a trace.  (4) the reference_mode variant (corners truncated to int before
+    the pose solve, corner_detections.cpp:53-54)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import orc_py
+    from robot_camera_calibration_amd import abi, api, synth
+    ncpu, quota, model = host_cpus()
+    T = max(1, min(ncpu, quota or ncpu, B))
+    S = min(B, a.cpu_sample if a.cpu_sample > 0 else (4 * T if fid else 8 * T))
+    SA = min(32, S)                      # frames compared in full whatever their status
+    host = frames[:S].cpu().numpy()
+    g_dets, g_fcs = det.detect(frames, B, want_corners=True)        # the GPU's answer for the WHOLE batch
+    by = {}
+    for d in g_dets:
+        by.setdefault(int(d.frame), []).append(d)
+    build = "-O3 -march=native"
+    try:
+        Lt = orc_py.native_library()
+    except Exception:
+        Lt, build = None, "-O2 (the -O3 -march=native build failed on this host)"
+    ctxs = [orc_py.Context(cfg, Lt) for _ in range(T)]
+    parts = [list(range(t, S, T)) for t in range(T)]
+
+    def work(t):
+        for f in parts[t]:
+            ctxs[t].detect(host[f], f)
+    rates = []
+    with ThreadPoolExecutor(T) as ex:
+        for _ in range(3):
+            t1 = time.perf_counter()
+            list(ex.map(work, range(T)))
+            rates.append(S / (time.perf_counter() - t1))
+    S1 = min(4, S)
+    r1 = []
+    for _ in range(3):
+        t2 = time.perf_counter()
+        for f in range(S1):
+            ctxs[0].detect(host[f], f)
+        r1.append(S1 / (time.perf_counter() - t2))
+    out["cpu_baseline"] = {"value": statistics.median(rates), "unit": "frames/s", "cores": T, "single_thread_value": statistics.median(r1), "kind": "port",
+                           "repetitions": 3, "all_rates": rates,
+                           "sample": "%d of the same %dx%d frames through oracle/ (C, %s, %d threads over frames, median of 3 repetitions); host: %s, %d logical CPUs usable%s" % (
+                               S, a.width, a.height, build, T, model or "unknown CPU", ncpu, (", cgroup quota %d" % quota) if quota else "")}
+
+    # ---- (3) status pass over every frame of the batch (the timing build: same sources, same -ffp-contract=off)
+    ostat = np.zeros((B, 3), np.int64)          # oracle: records, status, ncorners (board) / records, 0, sum of ids (tags)
+    t3 = time.perf_counter()
+    CH = 128
+    for c0 in range(0, B, CH):
+        hc = frames[c0:min(B, c0 + CH)].cpu().numpy()
+
+        def swork(t, hc=hc, c0=c0):
+            for i in range(t, len(hc), T):
+                n, od, ofc = ctxs[t].detect(hc[i], c0 + i)
+                ostat[c0 + i] = (n, ofc.status, ofc.ncorners) if not fid else (n, 0, sum(int(od[q].id) for q in range(n)))
+        with ThreadPoolExecutor(T) as ex:
+            list(ex.map(swork, range(T)))
+        del hc
+    full_rate = B / (time.perf_counter() - t3)
+    gstat = np.zeros((B, 3), np.int64)
+    for f in range(B):
+        g = by.get(f, [])
+        gstat[f] = (len(g), g_fcs[f].status, g_fcs[f].ncorners) if not fid else (len(g), 0, sum(int(d.id) for d in g))
+    incomplete = [f for f in range(B) if (gstat[f, 0] < tpf)]                  # frames that did not yield every target
+    status_mism = [f for f in range(B) if tuple(gstat[f]) != tuple(ostat[f])]
+    out["cpu_baseline"]["full_batch"] = {"value": full_rate, "unit": "frames/s", "frames": B,
+                                         "what": "the status pass over all %d frames (same build, %d threads, one pass, host copies of 128-frame chunks included)" % (B, T)}
+
+    # ---- (2) full comparison: the first SA frames + every frame that is incomplete or whose status disagrees
+    chk = orc_py.Context(cfg)                   # the checking build (oracle/liborc.so)
+    extra = sorted(set(incomplete + status_mism) - set(range(SA)))[:96]
+    acc = {"mism": 0, "corner": 0.0, "rvec": 0.0, "tvec": 0.0}
+    gtc = gtr = gtt = 0.0
+    Kb = np.array(list(cfg.K)); objb = synth.board_object_points(cfg.board_cols, cfg.board_rows, cfg.board_square)
+    nc = cfg.board_cols * cfg.board_rows
+    for f in list(range(SA)) + extra:
+        hf = host[f] if f < S else frames[f].cpu().numpy()
+        n, od, ofc = chk.detect(hf, f)
+        _frame_cmp(cfg, fid, f, by.get(f, []), g_fcs[f], n, od, ofc, acc)
+        if not fid and n and by.get(f):
+            # informational: against the analytic ground truth of the synthetic camera (undistorted image =
+            # pinhole projection of the board; the 9x7-square board has a 180-degree ambiguity)
+            gx = np.array([[g_fcs[f].xy[k][0], g_fcs[f].xy[k][1]] for k in range(nc)])
+            gt = synth.project_points(objb, poses[f][:3], poses[f][3:], Kb)
+            flip = np.abs(gx - gt).max() > np.abs(gx - gt[::-1]).max()
+            gtc = max(gtc, float(np.abs(gx - (gt[::-1] if flip else gt)).max()))
+            Rg = synth.rodrigues(poses[f][:3]) @ (np.diag([-1.0, -1.0, 1.0]) if flip else np.eye(3))
+            gtr = max(gtr, float(np.abs(synth.rodrigues(list(by[f][0].rvec)) - Rg).max()))
+            gtt = max(gtt, float(np.abs(np.array(list(by[f][0].tvec)) - poses[f][3:]).max()))
+    out["accuracy_vs_oracle"] = {"frames": SA + len(extra), "frames_what": "the first %d frames + %d incomplete / disagreeing frames of the batch" % (SA, len(extra)),
+                                 "max_corner_err_px": acc["corner"], "max_rvec_err": acc["rvec"], "max_tvec_err": acc["tvec"],
+                                 "corner_index_or_status_mismatches": acc["mism"],
+                                 "not_found_frames": incomplete[:64], "not_found_count": len(incomplete),
+                                 "status_mismatches_all_frames": len(status_mism), "status_mismatch_frames": status_mism[:64],
+                                 "all_frames_what": "oracle status pass over all %d frames: records per frame, frame status and corner count%s equal the detector's" % (B, " (tags: count and id sum)" if fid else "")}
+    if not fid:
+        out["accuracy_vs_ground_truth"] = {"frames": SA + len(extra), "max_corner_err_px": gtc, "max_rotation_matrix_err": gtr, "max_tvec_err_m": gtt,
+                                           "note": "informational: detector error on noisy supersampled renders, not a parity figure"}
+
+    # ---- (4) reference_mode: the reference casts the corners to int before solvePnP (corner_detections.cpp:53-54).
+    # Same frames, a detector and an oracle context with cfg.reference_mode = 1: parity of that variant, and what the
+    # truncation costs against the rendered pose (informational).
+    try:
+        cfgr = api.clone_config(cfg)
+        cfgr.reference_mode = 1
+        cfgr.batch_capacity = SA
+        detr = api.Detector(cfgr)
+        rd, rfc = detr.detect(frames[:SA].contiguous(), SA, want_corners=True)
+        detr.close()
+        rby = {}
+        for d in rd:
+            rby.setdefault(int(d.frame), []).append(d)
+        ocfg = api.clone_config(cfgr)
+        chkr = orc_py.Context(ocfg)
+        racc = {"mism": 0, "corner": 0.0, "rvec": 0.0, "tvec": 0.0}
+        dr = dt_ = 0.0
+        for f in range(SA):
+            n, od, ofc = chkr.detect(host[f], f)
+            _frame_cmp(cfgr, fid, f, rby.get(f, []), rfc[f], n, od, ofc, racc)
+            for q, d in enumerate(rby.get(f, [])):              # against the sub-pixel pose of the same target
+                sub = [x for x in by.get(f, []) if x.id == d.id]
+                if sub:
+                    dr = max(dr, float(np.abs(np.array(list(d.rvec)) - np.array(list(sub[0].rvec))).max()))
+                    dt_ = max(dt_, float(np.abs(np.array(list(d.tvec)) - np.array(list(sub[0].tvec))).max()))
+        chkr.close()
+        out["accuracy_reference_mode"] = {"frames": SA, "what": "cfg.reference_mode = 1: corners truncated to int before the pose solve, as corner_detections.cpp:53-54 does",
+                                          "max_rvec_err_vs_oracle": racc["rvec"], "max_tvec_err_vs_oracle": racc["tvec"], "mismatches": racc["mism"],
+                                          "max_rvec_shift_vs_subpixel_pose": dr, "max_tvec_shift_vs_subpixel_pose_m": dt_}
+    except Exception as e:
+        out["accuracy_reference_mode"] = {"error": repr(e)}
+    chk.close()
+    for c in ctxs:
+        c.close()
+
+
 def main():
     a = parse()
     if a.gpus < 1:
@@ -437,94 +607,9 @@ def main():
             out["extra_legs_error"] = repr(e)
 
     # ---- CPU baseline (the oracle = "port"; the reference's OpenCV path cannot be built here) and
-    # accuracy against it, on a bounded sample, rank 0 at N=1 only
+    # accuracy against it, rank 0 at N=1 only
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        from concurrent.futures import ThreadPoolExecutor
-        from oracle import orc_py
-        ncpu, quota, model = host_cpus()
-        T = max(1, min(ncpu, quota or ncpu, B))
-        S = min(B, a.cpu_sample if a.cpu_sample > 0 else (4 * T if fid else 8 * T))
-        SA = min(32, S)                      # frames also compared with the GPU records
-        host = frames[:S].cpu().numpy()
-        dets, fcs = det.detect(frames[:SA].contiguous(), SA, want_corners=True)
-        by = {}
-        for d in dets:
-            by.setdefault(int(d.frame), []).append(d)
-        build = "-O3 -march=native"
-        try:
-            Lt = orc_py.native_library()
-        except Exception:
-            Lt, build = None, "-O2 (the -O3 -march=native build failed on this host)"
-        ctxs = [orc_py.Context(cfg, Lt) for _ in range(T)]
-        parts = [list(range(t, S, T)) for t in range(T)]
-
-        def work(t):
-            for f in parts[t]:
-                ctxs[t].detect(host[f], f)
-        rates = []
-        with ThreadPoolExecutor(T) as ex:
-            for _ in range(3):
-                t1 = time.perf_counter()
-                list(ex.map(work, range(T)))
-                rates.append(S / (time.perf_counter() - t1))
-        S1 = min(4, S)
-        r1 = []
-        for _ in range(3):
-            t2 = time.perf_counter()
-            for f in range(S1):
-                ctxs[0].detect(host[f], f)
-            r1.append(S1 / (time.perf_counter() - t2))
-        out["cpu_baseline"] = {"value": statistics.median(rates), "unit": "frames/s", "cores": T, "single_thread_value": statistics.median(r1), "kind": "port",
-                               "repetitions": 3, "all_rates": rates,
-                               "sample": "%d of the same %dx%d frames through oracle/ (C, %s, %d threads over frames, median of 3 repetitions); host: %s, %d logical CPUs usable%s" % (
-                                   S, a.width, a.height, build, T, model or "unknown CPU", ncpu, (", cgroup quota %d" % quota) if quota else "")}
-        # accuracy: the checking build of the oracle (oracle/liborc.so) on SA frames
-        chk = orc_py.Context(cfg)
-        mxc = mxr = mxt = 0.0
-        gtc = gtr = gtt = 0.0
-        Kb = np.array(list(cfg.K)); objb = synth.board_object_points(cfg.board_cols, cfg.board_rows, cfg.board_square)
-        mism = 0
-        nc = cfg.board_cols * cfg.board_rows
-        for f in range(SA):
-            n, od, ofc = chk.detect(host[f], f)
-            if fid:
-                g = by.get(f, [])
-                if n != len(g):
-                    mism += 1
-                    continue
-                for q in range(n):
-                    if g[q].id != od[q].id:
-                        mism += 1
-                        continue
-                    mxc = max(mxc, float(np.abs(np.array(g[q].corners) - np.array([[od[q].corners[c][0], od[q].corners[c][1]] for c in range(4)])).max()))
-                    mxr = max(mxr, float(np.abs(np.array(list(g[q].rvec)) - np.array(list(od[q].rvec))).max()))
-                    mxt = max(mxt, float(np.abs(np.array(list(g[q].tvec)) - np.array(list(od[q].tvec))).max()))
-                continue
-            if (ofc.ncorners != fcs[f].ncorners) or (ofc.status != fcs[f].status):
-                mism += 1
-                continue
-            if n:
-                gp = np.array([[fcs[f].px[k][0], fcs[f].px[k][1]] for k in range(nc)])
-                op = np.array([[ofc.px[k][0], ofc.px[k][1]] for k in range(nc)])
-                mism += int((gp != op).any())
-                gx = np.array([[fcs[f].xy[k][0], fcs[f].xy[k][1]] for k in range(nc)])
-                ox = np.array([[ofc.xy[k][0], ofc.xy[k][1]] for k in range(nc)])
-                mxc = max(mxc, float(np.abs(gx - ox).max()))
-                mxr = max(mxr, float(np.abs(np.array(list(by[f][0].rvec)) - np.array(list(od.rvec))).max()))
-                mxt = max(mxt, float(np.abs(np.array(list(by[f][0].tvec)) - np.array(list(od.tvec))).max()))
-                # informational: against the analytic ground truth of the synthetic camera (undistorted image =
-                # pinhole projection of the board; the 9x7-square board has a 180-degree ambiguity)
-                gt = synth.project_points(objb, poses[f][:3], poses[f][3:], Kb)
-                flip = np.abs(gx - gt).max() > np.abs(gx - gt[::-1]).max()
-                gtc = max(gtc, float(np.abs(gx - (gt[::-1] if flip else gt)).max()))
-                Rg = synth.rodrigues(poses[f][:3]) @ (np.diag([-1.0, -1.0, 1.0]) if flip else np.eye(3))
-                gtr = max(gtr, float(np.abs(synth.rodrigues(list(by[f][0].rvec)) - Rg).max()))
-                gtt = max(gtt, float(np.abs(np.array(list(by[f][0].tvec)) - poses[f][3:]).max()))
-        out["accuracy_vs_oracle"] = {"frames": SA, "max_corner_err_px": mxc, "max_rvec_err": mxr, "max_tvec_err": mxt,
-                                     "corner_index_or_status_mismatches": mism}
-        if not fid:
-            out["accuracy_vs_ground_truth"] = {"frames": SA, "max_corner_err_px": gtc, "max_rotation_matrix_err": gtr, "max_tvec_err_m": gtt,
-                                               "note": "informational: detector error on noisy supersampled renders, not a parity figure"}
+        cpu_and_accuracy_legs(a, out, det, cfg, frames, poses, B, fid, tpf)
 
     if rank == 0:
         print(json.dumps(out))
