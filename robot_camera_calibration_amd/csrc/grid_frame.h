@@ -1,11 +1,18 @@
-// grid_frame.h -- the per-frame body of stages a4.3 + a6 (see k_grid.hip) as a device function, so that it can
-// run as its own kernel (k_validate_grid: stage API, any caller-supplied binary image) or in front of the board
-// pose solve in one kernel (k_grid_pnp in k_pnp.hip: both are one-wavefront-per-frame dependency chains, and a
-// frame's pose needs only that frame's lattice).
+// grid_frame.h -- the per-frame bodies of stages a4.3 and a6 (see k_grid.hip) as device functions.
+//   validate_frame: a4.3, spread over the 256 threads of a block (k_validate, k_grid.hip): one candidate per thread.
+//   index_frame:    a6, one wavefront per frame: as its own kernel (k_grid_index) or in front of the board pose solve in
+//                   one kernel (k_grid_pnp in k_pnp.hip: both are one-wavefront-per-frame dependency chains, and a frame's
+//                   pose needs only that frame's lattice).
+// They are separate launches because the pose solver's register budget (one wavefront per SIMD) would otherwise be paid by
+// the validation's helper wavefronts too: a 256-thread block with that budget fills a whole CU.
 #pragma once
 #include "rcc_internal.h"
 #include "wave_reduce.h"
 
+#ifndef GTRACE
+#define GTRACE(slot)
+#define GTRACE_VAL(slot, v)
+#endif
 #define GM 24
 #define GW (2 * GM + 1)
 #define GBOARD 16
@@ -83,68 +90,99 @@ __device__ __forceinline__ bool ring_ok(const BinSrc& b, int w, int h, int x, in
   return !any127 && tr == 4;
 }
 
-struct grid_smem {
-  int32_t px[RCC_MAX_KEPT], py[RCC_MAX_KEPT];
-  int32_t score[RCC_MAX_KEPT];
-  double xy[2 * RCC_MAX_KEPT];
-  int16_t rx[RCC_MAX_KEPT], ry[RCC_MAX_KEPT];
-  uint8_t ok[RCC_MAX_KEPT], keep[RCC_MAX_KEPT], used[RCC_MAX_KEPT], taken[RCC_MAX_KEPT];
-  int16_t lab[GW * GW];
-  int16_t qi[RCC_MAX_KEPT], qj[RCC_MAX_KEPT];
-  int16_t tmp[RCC_MAX_KEPT], t2[RCC_MAX_KEPT];
-  int32_t order[RCC_MAX_KEPT];
-};
+#define GRID_NOPOS 0x7FFF7FFFu                    // farther than any radius from every valid position (coordinates < 16384)
+#define LABP(i, j) sm.labp[((i) + GM) * GW + ((j) + GM)]
 
-#define LAB(i, j) sm.lab[((i) + GM) * GW + ((j) + GM)]
-
-// nearest point with used[k]==0 to (qx,qy); ties -> smaller index; returns -1 if none.
-// SMALL (w^2 + h^2 < 2^24: every distance between two image points fits 24 bits): the key (distance << 8 | index) is one
-// dword and the wave-wide minimum a 32-bit reduction -- half the instructions of the 64-bit form, in a loop that runs ~200
-// times per frame on a single wave.  A query outside the image may be farther than 2^24 - 2 from every point; its distance
-// saturates there, and such a match is refused by the caller either way (8 * distance > step^2, step^2 < 2^24).
-template <bool SMALL>
-__device__ __forceinline__ int nearest_free(const grid_smem& sm, int n, int lane, long long qx, long long qy, long long* dist)
+// ---- wave-uniform helpers: values that are the same in every lane live in scalar registers ------------------------------
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// lane l (uniform) of register jj (uniform, 0..3) of a 4-register array: point / queue entry lane + 64 * jj
+__device__ __forceinline__ int pick4(const int (&r)[4], int idx)
 {
-  if (SMALL) {
-    const int ix = (int)qx, iy = (int)qy;
-    unsigned best = ~0u;
-    for (int k = lane; k < n; k += 64) {
-      if (sm.used[k]) continue;
-      const int dx = sm.px[k] - ix, dy = sm.py[k] - iy;
-      const unsigned d = min((unsigned)(dx * dx) + (unsigned)(dy * dy), 0xFFFFFEu);
-      const unsigned key = (d << 8) | (unsigned)k;
-      best = key < best ? key : best;
-    }
-    best = wred::all_reduce32(best, [](unsigned a, unsigned b) { return a < b ? a : b; });
-    if (best == ~0u) return -1;
-    *dist = (long long)(best >> 8);
-    return (int)(best & 255u);
-  }
-  unsigned long long best = ~0ull;
-  for (int k = lane; k < n; k += 64) {
-    if (sm.used[k]) continue;
-    long long dx = (long long)sm.px[k] - qx, dy = (long long)sm.py[k] - qy;
-    unsigned long long key = ((unsigned long long)(dx * dx + dy * dy) << 8) | (unsigned long long)k;
-    best = key < best ? key : best;
-  }
-  best = wave_min_u64(best);
-  if (best == ~0ull) return -1;
-  *dist = (long long)(best >> 8);
-  return (int)(best & 255ull);
+  const int jj = idx >> 6, l = idx & 63;
+  return jj == 0 ? __builtin_amdgcn_readlane(r[0], l) : jj == 1 ? __builtin_amdgcn_readlane(r[1], l)
+       : jj == 2 ? __builtin_amdgcn_readlane(r[2], l) : __builtin_amdgcn_readlane(r[3], l);
+}
+__device__ __forceinline__ void put4(int (&r)[4], int idx, int val, int lane)
+{
+  const int jj = idx >> 6;
+  const bool mine = lane == (idx & 63);
+  if (jj == 0) r[0] = mine ? val : r[0];
+  else if (jj == 1) r[1] = mine ? val : r[1];
+  else if (jj == 2) r[2] = mine ? val : r[2];
+  else r[3] = mine ? val : r[3];
 }
 
-// returns true when the board lattice was found: its corners are then also at sm.xy[2 * sm.order[k]], k = 0..cols*rows-1
-__device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int lane,
-                                           const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
-                                           const uint8_t* __restrict__ thr, int nbands, int w, int h,
-                                           const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                           const double* __restrict__ pre_xy, int xj_check, int dedupe_radius,
-                                           int target_kind, int cols, int rows,
-                                           rcc_frame_corners* __restrict__ fc,
-                                           rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out)
+// The frame's validated points live in REGISTERS during the lattice growth: lane l holds points l, l + 64, l + 128,
+// l + 192 (pxr / pyr), their "used" flags as bits of one dword, and the lattice cell each was given.  The growth is a
+// single dependency chain per frame (~90 nearest-point searches one after the other); with the points in LDS every
+// search was a chain of LDS round trips (flags, coordinates, labels, queue), 73 us of this kernel.
+//
+// nearest point with its used bit clear to (qx, qy); ties -> smaller index; -1 if none.
+// SMALL (w^2 + h^2 < 2^24: every distance between two image points fits 24 bits): the key (distance << 8 | index) is one
+// dword and the wave-wide minimum a 32-bit reduction.  A query outside the image may be farther than 2^24 - 2 from every
+// point; its distance saturates there, and such a match is refused by the caller either way (8 * distance > step^2,
+// step^2 < 2^24).
+template <bool SMALL>
+__device__ __forceinline__ int nearest_free(const int (&pxr)[4], const int (&pyr)[4], const unsigned usedm, const int nk, const int lane,
+                                            const int qx, const int qy, long long* dist)
 {
+  if (SMALL) {
+    unsigned best = ~0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (64 * j >= nk) break;                       // uniform
+      const int k = lane + 64 * j;
+      const int dx = pxr[j] - qx, dy = pyr[j] - qy;
+      const unsigned d = min((unsigned)__mul24(dx, dx) + (unsigned)__mul24(dy, dy), 0xFFFFFEu);   // |dx|, |dy| < 2^14 here (SMALL: image below 4096 px, predictions within a step of it)
+      const unsigned key = (d << 8) | (unsigned)k;
+      const bool ok = (k < nk) && !((usedm >> j) & 1u);
+      best = (ok && key < best) ? key : best;
+    }
+    best = wred::all_reduce32(best, [](unsigned a, unsigned b) { return a < b ? a : b; });
+    const unsigned b = (unsigned)uni((int)best);
+    if (b == ~0u) return -1;
+    *dist = (long long)(b >> 8);
+    return (int)(b & 255u);
+  }
+  unsigned long long best = ~0ull;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (64 * j >= nk) break;
+    const int k = lane + 64 * j;
+    const long long dx = (long long)pxr[j] - qx, dy = (long long)pyr[j] - qy;
+    const unsigned long long key = ((unsigned long long)(dx * dx + dy * dy) << 8) | (unsigned long long)k;
+    const bool ok = (k < nk) && !((usedm >> j) & 1u);
+    best = (ok && key < best) ? key : best;
+  }
+  best = wave_min_u64(best);
+  const unsigned lo = (unsigned)uni((int)(unsigned)best), hi = (unsigned)uni((int)(unsigned)(best >> 32));
+  const unsigned long long b = (unsigned long long)lo | ((unsigned long long)hi << 32);
+  if (b == ~0ull) return -1;
+  *dist = (long long)(b >> 8);
+  return (int)(b & 255ull);
+}
+
+// ---- a4.3: validation of the refined corners of frame f, NT threads (one candidate per thread and pass): ring test at the
+// rounded refined position, de-duplication, ordered compaction into the frame's kept lists (global) + fc[f].nkept
+struct valid_smem {
+  int32_t score[RCC_MAX_KEPT];
+  uint32_t pos[RCC_MAX_KEPT];      // packed rounded refined pixel x | y << 16 of list entry i; GRID_NOPOS where it failed the ring test
+  uint8_t keep[RCC_MAX_KEPT];
+  int32_t wcnt[4];
+};
+template <int NT>
+__device__ __forceinline__ void validate_frame(valid_smem& sm, const int f, const int tid,
+                                               const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
+                                               const uint8_t* __restrict__ thr, int nbands, int w, int h,
+                                               const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
+                                               const double* __restrict__ pre_xy, int xj_check, int dedupe_radius,
+                                               rcc_frame_corners* __restrict__ fc,
+                                               rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out)
+{
+  static_assert(NT == 64 || NT == 256, "one or four wavefronts");
+  const int lane = tid & 63, wv = tid >> 6;
   rcc_frame_corners* out = fc + f;
-  if (out->status != 0) return false;   // overflow flagged by the list stage: the frame yields nothing
+  if (out->status != 0) return;         // overflow flagged by the list stage: the frame yields nothing
   BinSrc b;
   b.bin = bin ? bin + (size_t)f * w * h : nullptr;
   b.grey = grey + (size_t)f * w * h;
@@ -152,27 +190,28 @@ __device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int
   b.w = w; b.th = h >> 2;
   const int n = npre[f];
 
-  // ---- a4.3 validation at the rounded refined position
-  for (int i = lane; i < n; i += 64) {
+  for (int i = tid; i < n; i += NT) {
     const double x = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2], y = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2 + 1];
-    int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
-    sm.rx[i] = (int16_t)xi;
-    sm.ry[i] = (int16_t)yi;
+    const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
     sm.score[i] = pre[(size_t)f * RCC_MAX_KEPT + i].score;
     bool v = (xi >= 5 && yi >= 5 && xi < w - 5 && yi < h - 5);
     if (v && xj_check) v = ring_ok(b, w, h, xi, yi);
-    sm.ok[i] = v ? 1 : 0;
+    sm.pos[i] = v ? ((unsigned)xi | ((unsigned)yi << 16)) : GRID_NOPOS;
   }
   __syncthreads();
-  // (branch-free and unrolled: with an early exit every one of the ~80 iterations waited for its own LDS round trip:
-  // 31 -> 18 us of this one-wave-per-frame kernel; the decision is the same)
-  for (int i = lane; i < n; i += 64) {
-    bool keep = sm.ok[i];
-    const int xi = sm.rx[i], yi = sm.ry[i], si = sm.score[i];
+  // de-duplication: entry i goes if a valid entry within +-dedupe_radius has a larger score (or the same score and a smaller
+  // index).  An entry that failed the ring test sits at GRID_NOPOS, out of every valid entry's reach.  Branch-free and
+  // unrolled (an early exit made every iteration wait for its own LDS round trip).
+  for (int i = tid; i < n; i += NT) {
+    const unsigned pi = sm.pos[i];
+    const int xi = (int)(pi & 0xFFFFu), yi = (int)(pi >> 16), si = sm.score[i];
+    bool keep = pi != GRID_NOPOS;
 #pragma unroll 8
     for (int j = 0; j < n; ++j) {
-      const int dx = abs((int)sm.rx[j] - xi), dy = abs((int)sm.ry[j] - yi), sj = sm.score[j];
-      const bool beats = sm.ok[j] && (j != i) && (dx <= dedupe_radius) && (dy <= dedupe_radius) && (sj > si || (sj == si && j < i));
+      const unsigned pj = sm.pos[j];
+      const int sj = sm.score[j];
+      const int dx = abs((int)(pj & 0xFFFFu) - xi), dy = abs((int)(pj >> 16) - yi);
+      const bool beats = (j != i) && (dx <= dedupe_radius) && (dy <= dedupe_radius) && (sj > si || (sj == si && j < i));
       keep = keep && !beats;
     }
     sm.keep[i] = keep ? 1 : 0;
@@ -180,28 +219,56 @@ __device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int
   __syncthreads();
   // ordered compaction
   int m = 0;
-  for (int base = 0; base < n; base += 64) {
-    int i = base + lane;
-    bool k = (i < n) && sm.keep[i];
-    unsigned long long bal = __ballot(k);
-    if (k) {
-      int o = m + __popcll(bal & ((1ull << lane) - 1ull));
-      sm.px[o] = sm.rx[i];
-      sm.py[o] = sm.ry[i];
-      const double x = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2], y = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2 + 1];
-      sm.xy[2 * o] = x;
-      sm.xy[2 * o + 1] = y;
-      rcc_cand e;
-      e.x = sm.rx[i]; e.y = sm.ry[i]; e.score = sm.score[i];
-      kept_out[(size_t)f * RCC_MAX_KEPT + o] = e;
-      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2] = x;
-      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2 + 1] = y;
+  for (int base = 0; base < n; base += NT) {
+    const int i = base + tid;
+    const bool k = (i < n) && sm.keep[i];
+    const unsigned long long bal = __ballot(k);
+    int before = 0, total = __popcll(bal);
+    if (NT > 64) {
+      if (lane == 0) sm.wcnt[wv] = total;
+      __syncthreads();
+      total = 0;
+#pragma unroll
+      for (int q = 0; q < NT / 64; ++q) { const int c = sm.wcnt[q]; before += (q < wv) ? c : 0; total += c; }
     }
-    m += __popcll(bal);
+    if (k) {
+      const int o = m + before + __popcll(bal & ((1ull << lane) - 1ull));
+      const unsigned pi = sm.pos[i];
+      rcc_cand e;
+      e.x = (int16_t)(pi & 0xFFFFu); e.y = (int16_t)(pi >> 16); e.score = sm.score[i];
+      kept_out[(size_t)f * RCC_MAX_KEPT + o] = e;
+      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2] = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2];
+      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2 + 1] = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2 + 1];
+    }
+    m += total;
+    if (NT > 64) __syncthreads();        // wcnt is rewritten by the next pass
+  }
+  if (tid == 0) out->nkept = m;
+}
+
+// ---- a6: board indexing of frame f from its kept lists (validate_frame's output), ONE wavefront.  Returns true when the
+// board lattice was found: its corners are then also at sm.xy[2 * sm.order[k]], k = 0..cols*rows-1.
+struct grid_smem {
+  int32_t px[RCC_MAX_KEPT], py[RCC_MAX_KEPT];     // validated points (rounded refined pixel), in list order
+  double xy[2 * RCC_MAX_KEPT];
+  int32_t labp[GW * GW];                          // packed coordinates x | y << 16 of the point labelled (i, j); -1: empty
+  int16_t tmp[RCC_MAX_KEPT], t2[RCC_MAX_KEPT];
+  int32_t order[RCC_MAX_KEPT];
+};
+__device__ __forceinline__ bool index_frame(grid_smem& sm, const int f, const int lane, int w, int h,
+                                            const rcc_cand* __restrict__ kept, const double* __restrict__ kept_xy,
+                                            int target_kind, int cols, int rows, rcc_frame_corners* __restrict__ fc)
+{
+  rcc_frame_corners* out = fc + f;
+  if (out->status != 0) return false;   // overflow flagged by the list stage: the frame yields nothing
+  const int nk = uni(out->nkept);
+  for (int k = lane; k < nk && k < RCC_MAX_KEPT; k += 64) {
+    const rcc_cand e = kept[(size_t)f * RCC_MAX_KEPT + k];
+    sm.px[k] = e.x; sm.py[k] = e.y;
+    sm.xy[2 * k] = kept_xy[((size_t)f * RCC_MAX_KEPT + k) * 2];
+    sm.xy[2 * k + 1] = kept_xy[((size_t)f * RCC_MAX_KEPT + k) * 2 + 1];
   }
   __syncthreads();
-  const int nk = m;
-  if (lane == 0) out->nkept = nk;
 
   // ---- a6 board indexing
   const int need = cols * rows;
@@ -209,93 +276,131 @@ __device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int
   bool found_board = false;
   if (target_kind == RCC_TARGET_CHECKERBOARD && nk >= need && nk <= RCC_MAX_KEPT && cols >= 2 && rows >= 2 &&
       cols <= GBOARD && rows <= GBOARD && need <= RCC_MAX_BOARD_CORNERS) {
+    int pxr[4], pyr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = lane + 64 * j;
+      pxr[j] = (k < nk) ? sm.px[k] : 0;
+      pyr[j] = (k < nk) ? sm.py[k] : 0;
+    }
     long long sx = 0, sy = 0;
-    for (int i = lane; i < nk; i += 64) { sx += sm.px[i]; sy += sm.py[i]; sm.taken[i] = 0; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (lane + 64 * j < nk) { sx += pxr[j]; sy += pyr[j]; }
     sx = wave_sum_i64(sx);
     sy = wave_sum_i64(sy);
-    __syncthreads();
-    int seeds[8];
-    int nseeds = 0;
-    for (int s = 0; s < 8 && s < nk; ++s) {
+    // seeds: the 8 points nearest the centroid, nearest first; seed s is kept in lane s of seedreg
+    unsigned takenm = 0;
+    int seedreg = 0;
+    const int nseeds = nk < 8 ? nk : 8;
+    for (int s = 0; s < nseeds; ++s) {
       unsigned long long best = ~0ull;
-      for (int i = lane; i < nk; i += 64) {
-        if (sm.taken[i]) continue;
-        long long ex = (long long)nk * sm.px[i] - sx, ey = (long long)nk * sm.py[i] - sy;
-        unsigned long long key = ((unsigned long long)(ex * ex + ey * ey) << 8) | (unsigned long long)i;
-        best = key < best ? key : best;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nk && !((takenm >> j) & 1u)) {
+          const long long ex = (long long)nk * pxr[j] - sx, ey = (long long)nk * pyr[j] - sy;
+          const unsigned long long key = ((unsigned long long)(ex * ex + ey * ey) << 8) | (unsigned long long)i;
+          best = key < best ? key : best;
+        }
       }
       best = wave_min_u64(best);
-      int bi = (int)(best & 255ull);
-      if (lane == 0) sm.taken[bi] = 1;
-      __syncthreads();
-      seeds[nseeds++] = bi;
+      const int bi = uni((int)(best & 255ull));
+      if (lane == (bi & 63)) takenm |= 1u << (bi >> 6);
+      if (lane == s) seedreg = bi;
     }
+    GTRACE(1);
+    // packed cell offsets of the 3 x 3 neighbourhood a lane < 9 reads: cell (i + lane / 3 - 1, j + lane % 3 - 1)
+    const int nb_off = (lane < 9) ? ((lane / 3 - 1) * GW + (lane % 3 - 1)) : 0;
 
     for (int si = 0; si < nseeds && !found_board; ++si) {
-      const int s = seeds[si];
+      const int s = uni(__builtin_amdgcn_readlane(seedreg, si));
       __syncthreads();
-      for (int i = lane; i < nk; i += 64) sm.used[i] = (i == s) ? 1 : 0;
-      for (int i = lane; i < GW * GW; i += 64) sm.lab[i] = -1;
-      __syncthreads();
-      const long long sxp = sm.px[s], syp = sm.py[s];
+      for (int i = lane; i < GW * GW; i += 64) sm.labp[i] = -1;
+      unsigned usedm = (lane == (s & 63)) ? (1u << (s >> 6)) : 0u;
+      int cellr[4] = { 0, 0, 0, 0 };      // lattice cell (i + GM) | (j + GM) << 8 of the lane's points, where their used bit is set
+      int qreg[4] = { 0, 0, 0, 0 };       // the growth queue: entry e (a cell, packed as above) in lane e & 63 of register e >> 6
+      // give point k the cell (ti, tj): flags, the cell of the point, the label table (packed coordinates of the point)
+      auto claim = [&](const int k, const int ti, const int tj, const int packed_xy) {
+        const int cellp = (ti + GM) | ((tj + GM) << 8);
+        const bool mine = lane == (k & 63);
+        const int kj = k >> 6;
+        usedm |= mine ? (1u << kj) : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cellr[j] = (mine && j == kj) ? cellp : cellr[j];
+        if (lane == 0) LABP(ti, tj) = packed_xy;
+        return cellp;
+      };
+      const int sxp = pick4(pxr, s), syp = pick4(pyr, s);
       long long dd;
-      const int n1 = small ? nearest_free<true>(sm, nk, lane, sxp, syp, &dd) : nearest_free<false>(sm, nk, lane, sxp, syp, &dd);
+      const int n1 = small ? nearest_free<true>(pxr, pyr, usedm, nk, lane, sxp, syp, &dd) : nearest_free<false>(pxr, pyr, usedm, nk, lane, sxp, syp, &dd);
       if (n1 < 0) continue;
-      const long long ux = sm.px[n1] - sxp, uy = sm.py[n1] - syp;
+      const int n1x = pick4(pxr, n1), n1y = pick4(pyr, n1);
+      const long long ux = n1x - sxp, uy = n1y - syp;
       const long long uu = ux * ux + uy * uy;
       unsigned long long best = ~0ull;
-      for (int k = lane; k < nk; k += 64) {
-        if (k == s || k == n1) continue;
-        long long wx = sm.px[k] - sxp, wy = sm.py[k] - syp;
-        long long cr = ux * wy - uy * wx;
-        long long wwv = wx * wx + wy * wy;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = lane + 64 * j;
+        if (k >= nk || k == s || k == n1) continue;
+        const long long wx = pxr[j] - sxp, wy = pyr[j] - syp;
+        const long long cr = ux * wy - uy * wx;
+        const long long wwv = wx * wx + wy * wy;
         if (4 * cr * cr < uu * wwv) continue;
-        unsigned long long key = ((unsigned long long)wwv << 8) | (unsigned long long)k;
+        const unsigned long long key = ((unsigned long long)wwv << 8) | (unsigned long long)k;
         best = key < best ? key : best;
       }
       best = wave_min_u64(best);
-      if (best == ~0ull) continue;
-      const int n2 = (int)(best & 255ull);
-      const long long vx = sm.px[n2] - sxp, vy = sm.py[n2] - syp;
+      const unsigned blo = (unsigned)uni((int)(unsigned)best), bhi = (unsigned)uni((int)(unsigned)(best >> 32));
+      if (blo == ~0u && bhi == ~0u) continue;
+      const int n2 = (int)(blo & 255u);
+      const int n2x = pick4(pxr, n2), n2y = pick4(pyr, n2);
+      const long long vx = n2x - sxp, vy = n2y - syp;
 
-      int qh = 0, qt = 0;
-      if (lane == 0) {
-        LAB(0, 0) = (int16_t)s;  sm.qi[0] = 0; sm.qj[0] = 0;
-        LAB(1, 0) = (int16_t)n1; sm.qi[1] = 1; sm.qj[1] = 0; sm.used[n1] = 1;
-        LAB(0, 1) = (int16_t)n2; sm.qi[2] = 0; sm.qj[2] = 1; sm.used[n2] = 1;
-      }
-      qt = 3;
-      int L = 3;
-      __syncthreads();
+      put4(qreg, 0, claim(s, 0, 0, sxp | (syp << 16)), lane);
+      put4(qreg, 1, claim(n1, 1, 0, n1x | (n1y << 16)), lane);
+      put4(qreg, 2, claim(n2, 0, 1, n2x | (n2y << 16)), lane);
+      int qh = 0, qt = 3, L = 3;
+      __syncthreads();                 // the cleared table and the three labels are in place
+      GTRACE(3);
       while (qh < qt) {
-        const int i = sm.qi[qh], j = sm.qj[qh];
+        const int cell = pick4(qreg, qh);
         ++qh;
-        const int ai = LAB(i, j);
-        const long long ax = sm.px[ai], ay = sm.py[ai];
-#pragma unroll 1
+        const int i = (cell & 255) - GM, j = (cell >> 8) - GM;
+        // the 3 x 3 neighbourhood of (i, j) in ONE LDS round trip: lane c < 9 holds the packed coordinates of the point at
+        // cell (i + c / 3 - 1, j + c % 3 - 1), or -1.  Every rule below reads only these nine cells; a label set for
+        // direction d is patched into the register copy, so the later directions see it as the serial definition does.
+        int nbv = -1;
+        if (lane < 9) nbv = sm.labp[(i + GM) * GW + (j + GM) + nb_off];
+        const int a = __builtin_amdgcn_readlane(nbv, 4);
+        const int ax = a & 0xFFFF, ay = a >> 16;
+#pragma unroll
         for (int d = 0; d < 4; ++d) {
           const int di = (d == 0) ? 1 : (d == 1) ? -1 : 0;
           const int dj = (d == 2) ? 1 : (d == 3) ? -1 : 0;
           const int ti = i + di, tj = j + dj;
           if (ti < -GM + 1 || ti > GM - 1 || tj < -GM + 1 || tj > GM - 1) continue;
-          if (LAB(ti, tj) >= 0) continue;
-          long long predx = 0, predy = 0, step2 = 0;
+          const int tc = (1 + di) * 3 + (1 + dj);
+          if (__builtin_amdgcn_readlane(nbv, tc) >= 0) continue;
+          int predx = 0, predy = 0;
+          long long step2 = 0;
           bool have = false;
-          const int opp = LAB(i - di, j - dj);
+          const int opp = __builtin_amdgcn_readlane(nbv, (1 - di) * 3 + (1 - dj));
           if (opp >= 0) {
-            const long long bx = sm.px[opp], by = sm.py[opp];
+            const int bx = opp & 0xFFFF, by = opp >> 16;
             predx = 2 * ax - bx; predy = 2 * ay - by;
-            step2 = (ax - bx) * (ax - bx) + (ay - by) * (ay - by);
+            step2 = (long long)(ax - bx) * (ax - bx) + (long long)(ay - by) * (ay - by);
             have = true;
           }
           if (!have) {
-            for (int o = -1; o <= 1 && !have; o += 2) {
+#pragma unroll
+            for (int o = -1; o <= 1; o += 2) {
               const int oi = di ? 0 : o, oj = di ? o : 0;
-              const int c0 = LAB(i + oi, j + oj), c1 = LAB(i + oi + di, j + oj + dj);
-              if (c0 >= 0 && c1 >= 0) {
-                const long long ex = sm.px[c1] - sm.px[c0], ey = sm.py[c1] - sm.py[c0];
+              const int c0 = __builtin_amdgcn_readlane(nbv, (1 + oi) * 3 + (1 + oj));
+              const int c1 = __builtin_amdgcn_readlane(nbv, (1 + oi + di) * 3 + (1 + oj + dj));
+              if (!have && c0 >= 0 && c1 >= 0) {
+                const int ex = (c1 & 0xFFFF) - (c0 & 0xFFFF), ey = (c1 >> 16) - (c0 >> 16);
                 predx = ax + ex; predy = ay + ey;
-                step2 = ex * ex + ey * ey;
+                step2 = (long long)ex * ex + (long long)ey * ey;
                 have = true;
               }
             }
@@ -303,53 +408,52 @@ __device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int
           if (!have) {
             const long long ex = di ? ux : vx, ey = di ? uy : vy;
             const int sg = di ? di : dj;
-            predx = ax + sg * ex; predy = ay + sg * ey;
+            predx = ax + sg * (int)ex; predy = ay + sg * (int)ey;
             step2 = ex * ex + ey * ey;
           }
           long long dist = 0;
-          const int k = small ? nearest_free<true>(sm, nk, lane, predx, predy, &dist) : nearest_free<false>(sm, nk, lane, predx, predy, &dist);
+          const int k = small ? nearest_free<true>(pxr, pyr, usedm, nk, lane, predx, predy, &dist) : nearest_free<false>(pxr, pyr, usedm, nk, lane, predx, predy, &dist);
           if (k < 0) continue;
           if (8 * dist > step2) continue;
-          if (lane == 0) {
-            LAB(ti, tj) = (int16_t)k;
-            sm.used[k] = 1;
-            sm.qi[qt] = (int16_t)ti;
-            sm.qj[qt] = (int16_t)tj;
-          }
+          const int packed = pick4(pxr, k) | (pick4(pyr, k) << 16);
+          put4(qreg, qt, claim(k, ti, tj, packed), lane);
+          nbv = (lane == tc) ? packed : nbv;
           ++qt;
           ++L;
-          __syncthreads();
         }
       }
+      GTRACE(2); GTRACE_VAL(7, si * 1000 + L);
       if (L != need) continue;
-      // un-shear: first k in 0,1,-1,2,-2,3,-3 whose (i + k*j, j) box is cols x rows or rows x cols
+      // un-shear: first k in 0,1,-1,2,-2,3,-3 whose (i + k*j, j) box is cols x rows or rows x cols.  The labelled cells are
+      // the cells of the used points (L of them), each in the lane that holds the point.
       int found = 0, transpose = 0, imin = 0, jmin = 0, shear = 0;
+      int j0 = 1 << 20, j1 = -(1 << 20);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if ((usedm >> q) & 1u) { const int jj = (cellr[q] >> 8) - GM; j0 = min(j0, jj); j1 = max(j1, jj); }
+      j0 = wave_min_i32(j0); j1 = wave_max_i32(j1);
 #pragma unroll 1
       for (int t = 0; t < 7 && !found; ++t) {
         const int k = (t == 0) ? 0 : ((t & 1) ? (t + 1) / 2 : -(t / 2));
-        int i0 = 1 << 20, i1 = -(1 << 20), j0 = 1 << 20, j1 = -(1 << 20);
-        for (int c = lane; c < GW * GW; c += 64) {
-          if (sm.lab[c] < 0) continue;
-          int ii = c / GW - GM, jj = c % GW - GM;
-          int is = ii + k * jj;
+        int i0 = 1 << 20, i1 = -(1 << 20);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if ((usedm >> q) & 1u) {
+          const int ii = (cellr[q] & 255) - GM, jj = (cellr[q] >> 8) - GM;
+          const int is = ii + k * jj;
           i0 = min(i0, is); i1 = max(i1, is);
-          j0 = min(j0, jj); j1 = max(j1, jj);
         }
-        i0 = wave_min_i32(i0); i1 = wave_max_i32(i1);
-        j0 = wave_min_i32(j0); j1 = wave_max_i32(j1);
-        const int bw = i1 - i0 + 1, bh = j1 - j0 + 1;
+        i0 = uni(wave_min_i32(i0)); i1 = uni(wave_max_i32(i1));
+        const int bw = i1 - i0 + 1, bh = uni(j1) - uni(j0) + 1;
         if (bw == cols && bh == rows) { found = 1; transpose = 0; }
         else if (bw == rows && bh == cols) { found = 1; transpose = 1; }
-        if (found) { imin = i0; jmin = j0; shear = k; }
+        if (found) { imin = i0; jmin = uni(j0); shear = k; }
       }
       if (!found) continue;
-      for (int c = lane; c < GW * GW; c += 64) {
-        const int idx = sm.lab[c];
-        if (idx < 0) continue;
-        int ii = c / GW - GM, jj = c % GW - GM;
-        int a = ii + shear * jj - imin, bb = jj - jmin;
-        int cc = transpose ? bb : a, rr = transpose ? a : bb;
-        sm.tmp[rr * cols + cc] = (int16_t)idx;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if ((usedm >> q) & 1u) {
+        const int ii = (cellr[q] & 255) - GM, jj = (cellr[q] >> 8) - GM;
+        const int a2 = ii + shear * jj - imin, bb = jj - jmin;
+        const int cc = transpose ? bb : a2, rr = transpose ? a2 : bb;
+        sm.tmp[rr * cols + cc] = (int16_t)(lane + 64 * q);
       }
       __syncthreads();
       const int i00 = sm.tmp[0], ic = sm.tmp[cols - 1], ir = sm.tmp[(rows - 1) * cols];
@@ -382,4 +486,3 @@ __device__ __forceinline__ bool grid_frame(grid_smem& sm, const int f, const int
   }
   return found_board;
 }
-

@@ -18,7 +18,18 @@
 // hipcc -O3 miscompile that round 2 could not reproduce -- the fully inlined -O3 build passes every pose parity test
 // (the one recorded failure was the test's own: the Rodrigues round trip is not unique beyond |r| = pi) and is faster
 // (24 456 tag poses 0.45 -> 0.31 ms, board pose 0.27 -> 0.25 ms; profiles/r02_e_pnp_inline.txt).
+#ifdef RCC_EXPERIMENTS
+// experiment builds only: per-frame time stamps of k_grid_pnp's phases (rcc_debug_grid_trace): 16 slots per frame
+__device__ long long* g_grid_trace = nullptr;
+#define GTRACE(slot) do { if (g_grid_trace && lane == 0) g_grid_trace[(size_t)f * 16 + (slot)] = (long long)wall_clock64(); } while (0)
+#define GTRACE_VAL(slot, v) do { if (g_grid_trace && lane == 0) g_grid_trace[(size_t)f * 16 + (slot)] = (long long)(v); } while (0)
+// solver phases (pnp_core.h): k < 100 a time stamp in slot k; k >= 100: the refinement's iteration count into slot 13
+#define RCC_PNP_PHASE(k) do { if (g_grid_trace && threadIdx.x == 0) { if ((k) >= 100) g_grid_trace[(size_t)blockIdx.x * 16 + 13] = (k) - 100; else g_grid_trace[(size_t)blockIdx.x * 16 + (k)] = (long long)wall_clock64(); } } while (0)
+#endif
 #include "pnp_core.h"
+#ifdef RCC_EXPERIMENTS
+extern "C" hipError_t rcc_set_grid_trace(long long* d_buf) { return hipMemcpyToSymbol(HIP_SYMBOL(g_grid_trace), &d_buf, sizeof(d_buf)); }
+#endif
 #include "grid_frame.h"
 
 static __device__ __forceinline__ rccpnp::Cam to_cam(const rcc_cam& c)
@@ -140,15 +151,11 @@ __global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* 
                    img_scratch + (size_t)f * 2 * RCC_MAX_BOARD_CORNERS, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, det, ndet);
 }
 
-// a4.3 + a6 + a7 of one frame in one wavefront: board validation / lattice indexing (grid_frame.h), then the pose
-// from the lattice it leaves in LDS.  Both stages are single dependency chains per frame; run as two kernels the
-// second waits for the slowest frame of the first.
-__global__ __launch_bounds__(64) void k_grid_pnp(const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
-                                                 const uint8_t* __restrict__ thr, int nbands, int w, int h,
-                                                 const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                                 const double* __restrict__ pre_xy, int xj_check, int dedupe_radius,
+// a6 + a7 of one frame in one wavefront: lattice indexing of the validated corners (grid_frame.h), then the pose from the
+// lattice it leaves in LDS.  Both stages are single dependency chains per frame; run as two kernels the second waits for the
+// slowest frame of the first.  (a4.3, the validation, is a launch of its own: k_validate, one candidate per thread.)
+__global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* __restrict__ kept, const double* __restrict__ kept_xy,
                                                  int cols, int rows, rcc_frame_corners* __restrict__ fc,
-                                                 rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out,
                                                  const double* __restrict__ board_obj, double square, int board_id, int reference_mode,
                                                  rcc_cam cam, rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
 {
@@ -157,12 +164,14 @@ __global__ __launch_bounds__(64) void k_grid_pnp(const uint8_t* __restrict__ bin
   __shared__ double s_img[2 * RCC_MAX_BOARD_CORNERS];
   const int f = blockIdx.x;
   const int lane = threadIdx.x;
-  const bool found = grid_frame(sm, f, lane, bin, grey, thr, nbands, w, h, pre, npre, pre_xy, xj_check, dedupe_radius, RCC_TARGET_CHECKERBOARD,
-                                cols, rows, fc, kept_out, kept_xy_out);
+  GTRACE(0);
+  const bool found = index_frame(sm, f, lane, w, h, kept, kept_xy, RCC_TARGET_CHECKERBOARD, cols, rows, fc);
   __syncthreads();
+  GTRACE(5);
   if (!found) { if (lane == 0) ndet[f] = 0; return; }       // wave-uniform
   board_pose_frame(f, lane, [&](int k, double& x, double& y) { const int o = sm.order[k]; x = sm.xy[2 * o]; y = sm.xy[2 * o + 1]; },
                    s_img, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, det, ndet);
+  GTRACE(6);
 }
 
 __global__ __launch_bounds__(64) void k_pnp_generic_wave(const double* __restrict__ obj, const double* __restrict__ img,
@@ -269,20 +278,20 @@ hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s)
   return hipGetLastError();
 }
 
-// grid + board pose in one launch (wave per frame); same outputs as rcc_launch_grid followed by rcc_launch_pnp_board
+// validation, then lattice + board pose in one launch (wave per frame); same outputs as rcc_launch_grid followed by rcc_launch_pnp_board
 hipError_t rcc_launch_grid_pnp(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s)
 {
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
+  hipError_t e = rcc_launch_validate(h, d_grey, d_bin, nframes, s);
+  if (e != hipSuccess) return e;
   rcc_cam cam;
   cam.fx = c.K[0]; cam.cx = c.K[2]; cam.fy = c.K[4]; cam.cy = c.K[5];
   for (int i = 0; i < 8; ++i) cam.D[i] = c.D[i];
   cam.model = h->undist ? RCC_DIST_NONE : c.dist_model;
   cam.solver = h->pnp_solver;
-  const int nbands = (c.width + RCC_BAND_W - 1) / RCC_BAND_W;
-  hipLaunchKernelGGL(k_grid_pnp, dim3(nframes), dim3(64), 0, s, h->bin_from_thr ? nullptr : d_bin, d_grey,
-                     h->bin_from_thr ? h->d_thr : nullptr, nbands, c.width, c.height, h->d_pre, h->d_npre, h->d_pre_xy, c.xj_check, 2,
-                     c.board_cols, c.board_rows, h->d_fc, h->d_kept, h->d_kept_xy, h->d_board_obj, c.board_square, c.board_id,
+  hipLaunchKernelGGL(k_grid_pnp, dim3(nframes), dim3(64), 0, s, c.width, c.height, h->d_kept, h->d_kept_xy,
+                     c.board_cols, c.board_rows, h->d_fc, h->d_board_obj, c.board_square, c.board_id,
                      c.reference_mode, cam, h->d_det, h->d_ndet);
   return hipGetLastError();
 }

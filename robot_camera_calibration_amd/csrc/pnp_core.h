@@ -40,6 +40,10 @@
 #define RCC_DIST_FISHEYE 2
 #endif
 
+#ifndef RCC_PNP_PHASE
+#define RCC_PNP_PHASE(k)      /* experiment builds: a time stamp per solver phase (k_pnp.hip) */
+#endif
+
 namespace rccpnp {
 
 enum { PNP_OK = 0, PNP_TOO_FEW = 1, PNP_NONPLANAR = 2, PNP_DEGENERATE = 3 };
@@ -752,6 +756,7 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
 #ifdef RCC_PNP_TRACE_REFINE
   RCC_PNP_TRACE_REFINE(iter);
 #endif
+  RCC_PNP_PHASE(100 + iter);
 #pragma unroll
   for (int i = 0; i < 8; ++i) h[i] = x[i];
 }
@@ -821,7 +826,9 @@ RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const dou
 #pragma unroll
   for (int k = 0; k < 9; ++k) H[k] *= s;
   H[8] = 1.0;
+  RCC_PNP_PHASE(9);
   if (n > 4) homography_refine(par, H, p, Rt, Tt, cm, has_dist);
+  RCC_PNP_PHASE(10);
 #pragma unroll
   for (int k = 0; k < 9; ++k) if (!isfinite(H[k])) return 0;
   return 1;
@@ -909,7 +916,9 @@ RCC_NI RCC_HD inline int pose_init(const Par& par, const Pts& p, const Cam& cm, 
     for (int i = par.first(); i < n; i += par.step()) norm_point(p, i, cm, has_dist, nm[2 * i], nm[2 * i + 1]);
     pc.nm = nm;
   }
+  RCC_PNP_PHASE(8);
   if (find_homography(par, pc, Rt, Tt, cm, has_dist, H)) {
+    RCC_PNP_PHASE(11);
     double h1[3] = { H[0], H[3], H[6] }, h2[3] = { H[1], H[4], H[7] };
     t[0] = H[2]; t[1] = H[5]; t[2] = H[8];
     double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
@@ -1012,6 +1021,7 @@ RCC_HD inline int solve_pnp(const Par& par, const Pts& p, const Cam& cm_in, int 
     for (int k = 0; k < 3; ++k) { rvec[k] = 0.0; tvec[k] = 0.0; }
     return status;
   }
+  RCC_PNP_PHASE(12);
   ParAccum<Par> acc{ par, p, cm };
   double ss = 0.0;
   int it = pose_lm(prm, acc, cm.solver, &ss, par);

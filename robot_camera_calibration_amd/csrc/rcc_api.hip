@@ -739,6 +739,16 @@ int rcc_time_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes,
 }
 
 #ifdef RCC_EXPERIMENTS
+// experiment: per-frame phase time stamps of k_grid_pnp (8 x int64 per frame, wall_clock64 ticks of 10 ns): NULL switches off
+hipError_t rcc_set_grid_trace(long long* d_buf);
+int rcc_debug_grid_trace(rcc_handle* h, void* d_buf)
+{
+  if (!h) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, rcc_set_grid_trace((long long*)d_buf));
+  return RCC_OK;
+}
 // experiment: do the ingest pass (bandwidth-bound) and the threshold+corner pass (issue-bound) overlap when they are
 // launched on two streams over independent buffers?  mode 0: back to back on one stream; 1: concurrently.
 int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,
