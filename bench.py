@@ -49,6 +49,7 @@ def parse(argv=None):
     ap.add_argument("--pipeline", type=int, default=1, help="chunks of the detector's two-stream pipeline per step (1: single pass)")
     ap.add_argument("--fiducials", default="", help="BASELINE.json configs[4]-style run: GXxGY planar grid of square fiducials per frame, e.g. 6x4")
     ap.add_argument("--no-pin", action="store_true", help="do not bind the rank's host threads to its GPU's NUMA node")
+    ap.add_argument("--tag-refine", default="edges", choices=["edges", "subpix"], help="fiducial corner refinement: refine_edges form (default) or the cornerSubPix form")
     ap.add_argument("--fisheye", action="store_true", help="BASELINE.json configs[3]-style run: fisheye model (use with --width 3840 --height 2160 --batch 256)")
     return ap.parse_args(argv)
 
@@ -332,6 +333,22 @@ def cpu_and_accuracy_legs(a, out, det, cfg, frames, poses, B, fid, tpf):
                                  "not_found_frames": incomplete[:64], "not_found_count": len(incomplete),
                                  "status_mismatches_all_frames": len(status_mism), "status_mismatch_frames": status_mism[:64],
                                  "all_frames_what": "oracle status pass over all %d frames: records per frame, frame status and corner count%s equal the detector's" % (B, " (tags: count and id sum)" if fid else "")}
+    if fid:
+        # informational: against the rendered tags (the grid's layout through the frame's pose), first SA frames
+        (fhx, fhy), centres, ids = synth.fiducial_grid_layout(fid[0], fid[1], cfg.tag_size)
+        objt = synth.tag_object_points(cfg.tag_size)
+        ce, te = [], []
+        for f in range(SA):
+            Rg = synth.rodrigues(poses[f][:3])
+            for d in by.get(f, []):
+                c = centres[list(ids).index(int(d.id))]
+                gt = synth.project_points(objt + c, poses[f][:3], poses[f][3:], Kb)
+                ce.append(np.abs(np.array(d.corners) - gt).max())
+                te.append(np.abs(np.array(list(d.tvec)) - (Rg @ c + poses[f][3:])).max())
+        if ce:
+            out["accuracy_vs_ground_truth"] = {"frames": SA, "tags": len(ce), "max_corner_err_px": float(max(ce)), "median_corner_err_px": float(np.median(ce)),
+                                               "p90_corner_err_px": float(np.percentile(ce, 90)), "max_tvec_err_m": float(max(te)), "median_tvec_err_m": float(np.median(te)),
+                                               "note": "informational: detector error on noisy supersampled renders (per tag: largest coordinate error of its four corners), not a parity figure"}
     if not fid:
         out["accuracy_vs_ground_truth"] = {"frames": SA + len(extra), "max_corner_err_px": gtc, "max_rotation_matrix_err": gtr, "max_tvec_err_m": gtt,
                                            "note": "informational: detector error on noisy supersampled renders, not a parity figure"}
@@ -416,6 +433,7 @@ def main():
         fid = tuple(int(v) for v in a.fiducials.lower().split("x"))
         family = abi.load_family()
         abi.set_fiducial_target(cfg, family, tag_size=0.10, max_targets=fid[0] * fid[1])
+        cfg.tag_refine = abi.RCC_TAG_REFINE_EDGES if a.tag_refine == "edges" else abi.RCC_TAG_REFINE_CORNER_SUBPIX
     cfg.device = local
     cfg.batch_capacity = a.batch
     det = api.Detector(cfg)
@@ -499,7 +517,7 @@ def main():
             "dtype": "u8/i32 pixel stages, f64 sub-pixel + PnP", "data": "synthetic",
             "config": {"workload": workload_label(a, fid),
                        "frames_per_step_per_gpu": B,
-                       "target": ("%dx%d square fiducials of 0.10 m per frame (build family36b), 4-point PnP per tag" % fid) if fid else "8x6 inner-corner checkerboard, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
+                       "target": ("%dx%d square fiducials of 0.10 m per frame (build family36b), corners by %s, 4-point PnP per tag" % (fid + ("refine_edges" if a.tag_refine == "edges" else "cornerSubPix",))) if fid else "8x6 inner-corner checkerboard, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
                        "parallelism": "frame-sharded, 1 process per GPU, 1 all_gather of pose records (19 doubles per target slot, packed on the device) per step"},
             "targets_found_in_last_step": int(found), "targets_expected_per_step": int(world * B * tpf), "stage_ms_single_pass": timings, "pipeline_chunks": a.pipeline, "step_form": "sync detect()" if a.sync_steps else "submit/collect, one batch ahead", "value_with_sync_steps": sync_fps,
             "ranks": ranks,

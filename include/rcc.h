@@ -47,6 +47,18 @@ enum { RCC_PIX_MONO8 = 0, RCC_PIX_BGR8 = 1 };
 enum { RCC_DIST_NONE = 0, RCC_DIST_PLUMB_BOB = 1, RCC_DIST_FISHEYE = 2 };
 enum { RCC_TARGET_CHECKERBOARD = 0, RCC_TARGET_FIDUCIAL = 1 };
 enum { RCC_MEM_HOST = 0, RCC_MEM_DEVICE = 1 };
+/* how the four corners of a square fiducial are refined (rcc_config.tag_refine):
+ *   EDGES (default)  apriltag's refine_edges form: quads are found on coarsely localised corner
+ *                    candidates (a5 cut to RCC_TAG_COARSE_ITERS iterations); per edge 16 samples search along the normal
+ *                    for the gradient-weighted edge position, a total-least-squares line goes through them, and the
+ *                    corners are the intersections of adjacent lines;
+ *   CORNER_SUBPIX    every suppressed candidate goes through the cornerSubPix form of a5 first (the board's refinement,
+ *                    run at an L-corner) and quads are found on the refined positions: rounds 1-2 of this build. */
+enum { RCC_TAG_REFINE_EDGES = 0, RCC_TAG_REFINE_CORNER_SUBPIX = 1 };
+/* EDGES: the a5 pass in front of the quad search is cut to a coarse localisation -- classification and linking work on
+ * positions rounded to a pixel, the reported corners come from the edges */
+#define RCC_TAG_COARSE_ITERS 2
+#define RCC_TAG_COARSE_EPS   0.1
 
 /* per-frame status word (bit flags) */
 enum {
@@ -130,7 +142,8 @@ typedef struct rcc_config {
   double  tag_size;              /* metres, side of the black square: the four reported corners are its
                                     corners and the object points are (+-tag_size/2, +-tag_size/2, 0)
                                     (camera_pose.cpp:158-161) */
-  int32_t reserved[2];
+  int32_t tag_refine;            /* RCC_TAG_REFINE_*: corner refinement of fiducial quads (was reserved[0]: 0 = EDGES) */
+  int32_t reserved[1];
 } rcc_config;
 
 /* ---- result records (POD) ------------------------------------------------------------------ */

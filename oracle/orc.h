@@ -71,7 +71,8 @@ int orc_fid_homography(const double q[8], double H[9]);
 int orc_fid_decode(const uint8_t* g, int w, int h, const double q[8], const uint64_t* codes, int ncodes,
                    int max_hamming, int* id_out, int* ham_out, int* rot_out);
 int orc_fid_detect(const uint8_t* grey, int w, int h, int min_contrast, const orc_cand* pre, const double* xy,
-                   int n, const uint64_t* codes, int ncodes, int max_hamming, rcc_detection* out, int cap);
+                   int n, const uint64_t* codes, int ncodes, int max_hamming, int refine_mode, rcc_detection* out, int cap);
+void orc_fid_refine_edges(const uint8_t* g, int w, int h, const int qi[8], double qr[8]);
 
 /* ---- a7 / a8 pose ---- */
 void orc_rodrigues_v2m(const double r[3], double R[9], double J[27]);  /* J: 3x9, may be NULL */

@@ -99,14 +99,24 @@ int orc_ctx_detect(orc_ctx* c, const uint8_t* frame, int frame_index, rcc_detect
   if (pre_out) memcpy(pre_out, c->pre, sizeof(orc_cand) * (size_t)npre);
   double* pxy = c->pxy;
   double xy[2 * 256];
-  orc_corner_subpix(c->grey, w, h, c->pre, npre, cfg->subpix_win, cfg->subpix_max_iter, cfg->subpix_eps, pxy);
+  const int tag_edges = (cfg->target_kind == RCC_TARGET_FIDUCIAL) && (cfg->tag_refine == RCC_TAG_REFINE_EDGES);
+  if (tag_edges) {
+    /* refine_edges form: the a5 pass only has to bring a candidate within a pixel of its corner (classification and linking
+     * work on rounded positions; the reported corners come from the edges): at most RCC_TAG_COARSE_ITERS iterations, stop below
+     * RCC_TAG_COARSE_EPS px */
+    const int it = cfg->subpix_max_iter < RCC_TAG_COARSE_ITERS ? cfg->subpix_max_iter : RCC_TAG_COARSE_ITERS;
+    const double eps = cfg->subpix_eps > RCC_TAG_COARSE_EPS ? cfg->subpix_eps : RCC_TAG_COARSE_EPS;
+    orc_corner_subpix(c->grey, w, h, c->pre, npre, cfg->subpix_win, it, eps, pxy);
+  } else {
+    orc_corner_subpix(c->grey, w, h, c->pre, npre, cfg->subpix_win, cfg->subpix_max_iter, cfg->subpix_eps, pxy);
+  }
   if (pre_xy_out) memcpy(pre_xy_out, pxy, sizeof(double) * 2 * (size_t)npre);
   if (cfg->target_kind == RCC_TARGET_FIDUCIAL) {
     /* a4/a6 square-fiducial form + a7 per tag (4 corners bl,br,tr,tl; camera_pose.cpp:152-163) */
     const int cap = cfg->max_targets;
     rcc_detection* tmp = (rcc_detection*)malloc(sizeof(rcc_detection) * (size_t)(cap > 0 ? cap : 1));
     int m = orc_fid_detect(c->grey, w, h, cfg->thr_min_contrast, c->pre, pxy, npre, cfg->family_codes, cfg->family_n,
-                           cfg->tag_max_hamming, tmp, cap);
+                           cfg->tag_max_hamming, cfg->tag_refine, tmp, cap);
     if (m > cap) m = cap;
     const double s2 = 0.5 * cfg->tag_size;
     const double obj[12] = { -s2, -s2, 0, s2, -s2, 0, s2, s2, 0, -s2, s2, 0 };

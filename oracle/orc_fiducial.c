@@ -185,22 +185,133 @@ int orc_fid_decode(const uint8_t* g, int w, int h, const double q[8], const uint
   return 1;
 }
 
+/* ---- corner refinement of a quad in the refine_edges form (SURVEY.md appendix C.4 [U]: per edge >= 16 samples; at each,
+ * a scan along the normal in 0.25-px steps, weights (g2 - g1)^2 of the correct polarity, weighted-mean offset; a total-
+ * least-squares line through the refined points; corners = intersections of adjacent lines).  Restated [B] so that every
+ * decision is an integer and every floating-point step one rounded IEEE operation (+ - * / sqrt, -ffp-contract=off):
+ *   qi        the quad's integer corners (x, y), clockwise on screen; black lies on the (-dy, dx) side of every edge a -> b
+ *   samples   16 per edge at a + alpha (b - a), alpha = (s + 2) / 19, s = 0..15 (the two positions nearest either corner are
+ *             left out: there the other edge bends the profile)
+ *   scan      offsets k / 4 px along the OUTWARD normal n = (dy, -dx) / |d|, k = -12 .. 12; g1 = the image one pixel further
+ *             out, g2 = one pixel further in, both sampled bilinearly in 1/16-px fixed point as 256 x grey (bil16; a step
+ *             whose samples leave the image is skipped); weight (g1 - g2)^2 where g1 > g2 (white outside), else 0;
+ *             offset = (sum k w / sum w) / 4  -- integer sums
+ *   line      moments of the refined points relative to a, summed over the 16 samples along the pairing tree
+ *             v[l] += v[l ^ 8], ^ 4, ^ 2, ^ 1 (what a 16-lane butterfly does); centroid E, covariance C; the normal is the
+ *             eigenvector of C's smaller eigenvalue, taken in its well-conditioned form; fewer than 4 valid samples or a
+ *             vanishing normal: the line through the integer corners
+ *   corners   corner c = intersection of the lines of edges c - 1 and c, solved relative to qi[c]; kept at the integer
+ *             corner if the lines are (nearly) parallel or the intersection lies more than 4 px away from it */
+/* 256 x grey at (px, py), bilinear with the position rounded to 1/16 px (0 <= px <= w - 2, 0 <= py <= h - 2) */
+static int bil16(const uint8_t* g, int w, double px, double py)
+{
+  const int X = (int)rint(px * 16.0), Y = (int)rint(py * 16.0);
+  const int ix = X >> 4, iy = Y >> 4, fx = X & 15, fy = Y & 15;
+  const uint8_t* p = g + (size_t)iy * w + ix;
+  return (16 - fx) * (16 - fy) * p[0] + fx * (16 - fy) * p[1] + (16 - fx) * fy * p[w] + fx * fy * p[w + 1];   /* 256 x grey */
+}
+static double tree16(double* v)
+{
+  for (int off = 8; off >= 1; off >>= 1) {
+    double nv[16];
+    for (int l = 0; l < 16; ++l) nv[l] = v[l] + v[l ^ off];
+    for (int l = 0; l < 16; ++l) v[l] = nv[l];
+  }
+  return v[0];
+}
+
+static void refine_edges_pass(const uint8_t* g, int w, int h, const double qi[8], double qr[8])
+{
+  double E[4][2], V[4][2];         /* per edge: a point of the line (absolute) and its normal (any length) */
+  for (int e = 0; e < 4; ++e) {
+    const double ax = qi[2 * e], ay = qi[2 * e + 1], bx = qi[2 * ((e + 1) & 3)], by = qi[2 * ((e + 1) & 3) + 1];
+    const double dx = bx - ax, dy = by - ay;
+    const double dxx = dx * dx, dyy = dy * dy;
+    const double L = sqrt(dxx + dyy);
+    double nx = 0.0, ny = 0.0;
+    if (L > 0.0) { nx = dy / L; ny = -dx / L; }
+    double sx[16], sy[16], sxx[16], sxy[16], syy[16], sn[16];
+    for (int s = 0; s < 16; ++s) {
+      const double alpha = (double)(s + 2) / 19.0;
+      const double tx = alpha * dx, ty = alpha * dy;
+      const double x0 = ax + tx, y0 = ay + ty;
+      long long Mn = 0, Mc = 0;
+      for (int k = -12; k <= 12; ++k) {
+        const double t1 = (double)(k + 4) * 0.25, t2 = (double)(k - 4) * 0.25;
+        const double u1 = t1 * nx, v1 = t1 * ny, u2 = t2 * nx, v2 = t2 * ny;
+        const double x1 = x0 + u1, y1 = y0 + v1, x2 = x0 + u2, y2 = y0 + v2;
+if (!(x1 >= 0.0 && y1 >= 0.0 && x1 <= (double)(w - 2) && y1 <= (double)(h - 2) &&
+              x2 >= 0.0 && y2 >= 0.0 && x2 <= (double)(w - 2) && y2 <= (double)(h - 2))) continue;
+        const int g1 = bil16(g, w, x1, y1), g2 = bil16(g, w, x2, y2);
+        if (g1 <= g2) continue;
+        const long long wt = (long long)(g1 - g2) * (g1 - g2);
+        Mn += wt * k; Mc += wt;
+      }
+      if (Mc == 0 || !(L > 0.0)) { sx[s] = sy[s] = sxx[s] = sxy[s] = syy[s] = sn[s] = 0.0; continue; }
+      const double n0 = ((double)Mn / (double)Mc) * 0.25;
+      const double ox = n0 * nx, oy = n0 * ny;
+      const double rx = tx + ox, ry = ty + oy;          /* refined point relative to a */
+      sx[s] = rx; sy[s] = ry; sxx[s] = rx * rx; sxy[s] = rx * ry; syy[s] = ry * ry; sn[s] = 1.0;
+    }
+    const double N = tree16(sn), Sx = tree16(sx), Sy = tree16(sy), Sxx = tree16(sxx), Sxy = tree16(sxy), Syy = tree16(syy);
+    E[e][0] = ax; E[e][1] = ay; V[e][0] = nx; V[e][1] = ny;      /* fallback: the edge as given */
+    if (N >= 4.0) {
+      const double Ex = Sx / N, Ey = Sy / N;
+      const double Cxx = Sxx / N - Ex * Ex, Cxy = Sxy / N - Ex * Ey, Cyy = Syy / N - Ey * Ey;
+      const double hd = (Cxx - Cyy) * 0.5;
+      const double r = sqrt(hd * hd + Cxy * Cxy);
+      double vx, vy;
+      if (hd >= 0.0) { vx = Cxy; vy = -hd - r; } else { vx = hd - r; vy = Cxy; }
+      const double vv = vx * vx + vy * vy;
+      if (vv > 1e-12) { E[e][0] = ax + Ex; E[e][1] = ay + Ey; V[e][0] = vx; V[e][1] = vy; }
+    }
+  }
+  for (int c = 0; c < 4; ++c) {
+    const int a = (c + 3) & 3, b = c;           /* edges a (arriving at corner c) and b (leaving it) */
+    const double cx = qi[2 * c], cy = qi[2 * c + 1];
+    const double ea = V[a][0] * (E[a][0] - cx) + V[a][1] * (E[a][1] - cy);
+    const double eb = V[b][0] * (E[b][0] - cx) + V[b][1] * (E[b][1] - cy);
+    const double det = V[a][0] * V[b][1] - V[a][1] * V[b][0];
+    const double na = V[a][0] * V[a][0] + V[a][1] * V[a][1], nb = V[b][0] * V[b][0] + V[b][1] * V[b][1];
+    double px = 0.0, py = 0.0;
+    int ok = det * det > 1e-6 * (na * nb);      /* sin^2 of the angle between the lines > 1e-6 */
+    if (ok) {
+      px = (ea * V[b][1] - eb * V[a][1]) / det;
+      py = (V[a][0] * eb - V[b][0] * ea) / det;
+      ok = (px * px + py * py <= 16.0);
+    }
+    qr[2 * c] = ok ? cx + px : cx;
+    qr[2 * c + 1] = ok ? cy + py : cy;
+  }
+}
+
+void orc_fid_refine_edges(const uint8_t* g, int w, int h, const int qi[8], double qr[8])
+{
+  double q0[8];
+  for (int k = 0; k < 8; ++k) q0[k] = (double)qi[k];
+  refine_edges_pass(g, w, h, q0, qr);
+}
+
 int orc_fid_detect_dbg(const uint8_t* grey, int w, int h, int min_contrast, const orc_cand* pre, const double* xy,
-                       int n, const uint64_t* codes, int ncodes, int max_hamming, rcc_detection* out, int cap,
+                       int n, const uint64_t* codes, int ncodes, int max_hamming, int refine_mode, rcc_detection* out, int cap,
                        int32_t* dbg_ok, int32_t* dbg_nxt);
 
 /* whole fiducial stage for one frame.  pre: suppressed candidate list (sorted by (y,x)), xy: their
  * refined positions.  Writes up to cap records {id, hamming, corners bl,br,tr,tl}; returns the count. */
 int orc_fid_detect(const uint8_t* grey, int w, int h, int min_contrast, const orc_cand* pre, const double* xy,
-                   int n, const uint64_t* codes, int ncodes, int max_hamming, rcc_detection* out, int cap)
+                   int n, const uint64_t* codes, int ncodes, int max_hamming, int refine_mode, rcc_detection* out, int cap)
 {
-  return orc_fid_detect_dbg(grey, w, h, min_contrast, pre, xy, n, codes, ncodes, max_hamming, out, cap, NULL, NULL);
+  return orc_fid_detect_dbg(grey, w, h, min_contrast, pre, xy, n, codes, ncodes, max_hamming, refine_mode, out, cap, NULL, NULL);
 }
 
+/* Corners are classified and linked at the rounded positions xy (the a5 pass: coarse for RCC_TAG_REFINE_EDGES, full for
+ * RCC_TAG_REFINE_CORNER_SUBPIX).  EDGES: each quad's corners come from orc_fid_refine_edges started at those rounded
+ * positions; CORNER_SUBPIX: the refined positions themselves are the reported corners. */
 int orc_fid_detect_dbg(const uint8_t* grey, int w, int h, int min_contrast, const orc_cand* pre, const double* xy,
-                       int n, const uint64_t* codes, int ncodes, int max_hamming, rcc_detection* out, int cap,
+                       int n, const uint64_t* codes, int ncodes, int max_hamming, int refine_mode, rcc_detection* out, int cap,
                        int32_t* dbg_ok, int32_t* dbg_nxt)
 {
+  const int edges = (refine_mode == RCC_TAG_REFINE_EDGES);
   if (n > RCC_MAX_KEPT_FIDUCIAL) n = RCC_MAX_KEPT_FIDUCIAL;
   int* px = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1) * 7);
   int* py = px + n; int* ok = py + n; int* d1x = ok + n; int* d1y = d1x + n; int* nxt = d1y + n;
@@ -244,7 +355,15 @@ int orc_fid_detect_dbg(const uint8_t* grey, int w, int h, int min_contrast, cons
     if (!(i < j && i < k && i < l)) continue;                  /* emit each cycle once, from its smallest index */
     const int idx[4] = { i, j, k, l };
     double q[8];
-    for (int c = 0; c < 4; ++c) { q[2 * c] = xy[2 * idx[c]]; q[2 * c + 1] = xy[2 * idx[c] + 1]; }
+    if (edges) {
+      int qi[8];
+      for (int c = 0; c < 4; ++c) { qi[2 * c] = px[idx[c]]; qi[2 * c + 1] = py[idx[c]]; }
+      const long long cri = (long long)(qi[2] - qi[0]) * (qi[5] - qi[3]) - (long long)(qi[3] - qi[1]) * (qi[4] - qi[2]);
+      if (!(cri > 0)) continue;                                   /* clockwise on screen (on the integer corners) */
+      orc_fid_refine_edges(grey, w, h, qi, q);
+    } else {
+      for (int c = 0; c < 4; ++c) { q[2 * c] = xy[2 * idx[c]]; q[2 * c + 1] = xy[2 * idx[c] + 1]; }
+    }
     const double cr = (q[2] - q[0]) * (q[5] - q[3]) - (q[3] - q[1]) * (q[4] - q[2]);
     if (!(cr > 0.0)) continue;                                    /* clockwise on screen */
     int id, ham, rot;

@@ -241,6 +241,16 @@ def jacobi_eigen_sym(A):
     return w, V
 
 
+def fid_refine_edges(grey, qi):
+    """refine_edges form of the tag-corner refinement: grey (h, w) uint8, qi 4 x 2 integer corners clockwise on screen"""
+    h, w = grey.shape
+    g = np.ascontiguousarray(grey, np.uint8)
+    q = np.ascontiguousarray(np.asarray(qi, np.int32).reshape(8))
+    out = np.zeros(8)
+    lib().orc_fid_refine_edges(_p(g), C.c_int(w), C.c_int(h), _p(q), _p(out))
+    return out.reshape(4, 2)
+
+
 def synth_render(cfg, sp, pose, frame_index):
     ch = 3 if cfg.pixfmt == abi.RCC_PIX_BGR8 else 1
     out = np.zeros((cfg.height, cfg.stride_bytes), np.uint8)

@@ -42,7 +42,8 @@ class rcc_config(C.Structure):
         ("family_n", C.c_int32), ("tag_max_hamming", C.c_int32),
         ("family_codes", C.c_void_p),
         ("tag_size", C.c_double),
-        ("reserved", C.c_int32 * 2),
+        ("tag_refine", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 
@@ -121,6 +122,7 @@ FISHEYE_DEFAULT = (-0.02, 0.005, -0.001, 0.0002)          # SURVEY 8(d), config 
 
 
 RCC_MAX_KEPT_FIDUCIAL = 2048
+RCC_TAG_REFINE_EDGES, RCC_TAG_REFINE_CORNER_SUBPIX = 0, 1
 _FAMILY_CACHE = {}
 
 

@@ -231,11 +231,120 @@ __device__ bool fid_decode_group(const uint8_t* __restrict__ g, int w, int h, co
   return true;
 }
 
+// ---- corner refinement of a quad in the refine_edges form (SURVEY.md appendix C.4 [U]: per edge >= 16 samples; at each, a
+// scan along the normal in 0.25-px steps, weights (g2 - g1)^2 of the correct polarity, weighted-mean offset; a total-least-
+// squares line through the refined points; corners = intersections of adjacent lines), restated [B] so that every decision
+// is an integer and every floating-point step one rounded IEEE operation (+ - * / sqrt; -ffp-contract=off):
+//   qi        the quad's corners rounded to pixels, clockwise on screen; black lies on the (-dy, dx) side of every edge a -> b
+//   samples   16 per edge at a + alpha (b - a), alpha = (s + 2) / 19, s = 0..15 (the two positions nearest either corner are
+//             left out: there the other edge bends the profile)
+//   scan      33 bilinear samples (1/16-px fixed point, 256 x grey) along the OUTWARD normal n = (dy, -dx) / |d| at offsets
+//             j / 4 px, j = -16 .. 16; step k = -12 .. 12 pairs j = k + 4 (one pixel further out) with j = k - 4 (further in):
+//             weight (g1 - g2)^2 where g1 > g2 (white outside) and both samples lie inside the image, else 0;
+//             offset = (sum k w / sum w) / 4 -- integer sums
+//   line      moments of the refined points relative to a, summed over the 16 samples along the pairing tree of a 16-lane
+//             xor butterfly (offsets 8, 4, 2, 1; IEEE addition commutes, so every lane ends with the same totals);
+//             centroid E, covariance C; the normal is the eigenvector of C's smaller eigenvalue in its well-conditioned
+//             form; fewer than 4 valid samples or a vanishing normal: the line through the rounded corners
+//   corners   corner c = intersection of the lines of edges c - 1 and c, solved relative to qi[c]; kept at qi[c] if the lines
+//             are (nearly) parallel or the intersection lies more than 4 px away
+// The 16 lanes of a decode group share one quad: lane s takes sample s of each of the four edges in turn; the line fit and the
+// intersections are computed by every lane alike.  The CPU restatement the tests compare with follows the same steps, so
+// the corners are the same bits.
+__device__ __forceinline__ double fid_tree16(double v)
+{
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 16);
+  return v;
+}
+// 256 x grey at (px, py), position rounded to 1/16 px; the two taps of a row in one (unaligned) 16-bit load
+__device__ __forceinline__ int fid_bil16(const uint8_t* __restrict__ g, int w, double px, double py)
+{
+  const int X = (int)rint(px * 16.0), Y = (int)rint(py * 16.0);
+  const int ix = X >> 4, iy = Y >> 4, fx = X & 15, fy = Y & 15;
+  const uint8_t* p = g + (size_t)iy * w + ix;
+  unsigned short r0, r1;
+  __builtin_memcpy(&r0, p, 2);
+  __builtin_memcpy(&r1, p + w, 2);
+  return (16 - fx) * (16 - fy) * (int)(r0 & 255) + fx * (16 - fy) * (int)(r0 >> 8) + (16 - fx) * fy * (int)(r1 & 255) + fx * fy * (int)(r1 >> 8);
+}
+__device__ void fid_refine_edges_group(const uint8_t* __restrict__ g, int w, int h, const int qi[8], int s /* lane of the group = sample */, bool valid, double qr[8])
+{
+  double E[4][2], V[4][2];
+#pragma unroll 1
+  for (int e = 0; e < 4; ++e) {
+    const double ax = (double)qi[2 * e], ay = (double)qi[2 * e + 1], bx = (double)qi[2 * ((e + 1) & 3)], by = (double)qi[2 * ((e + 1) & 3) + 1];
+    const double dx = bx - ax, dy = by - ay;
+    const double dxx = dx * dx, dyy = dy * dy;
+    const double L = sqrt(dxx + dyy);
+    double nx = 0.0, ny = 0.0;
+    if (L > 0.0) { nx = dy / L; ny = -dx / L; }
+    const double alpha = (double)(s + 2) / 19.0;
+    const double tx = alpha * dx, ty = alpha * dy;
+    const double x0 = ax + tx, y0 = ay + ty;
+    int P[33];                                   // 256 x grey at offset j / 4 along the normal, -1 outside the image
+#pragma unroll
+    for (int j = -16; j <= 16; ++j) {
+      const double t = (double)j * 0.25;
+      const double u = t * nx, v = t * ny;
+      const double x = x0 + u, y = y0 + v;
+      const bool in = valid && x >= 0.0 && y >= 0.0 && x <= (double)(w - 2) && y <= (double)(h - 2);
+      P[j + 16] = in ? fid_bil16(g, w, x, y) : -1;
+    }
+    long long Mn = 0, Mc = 0;
+#pragma unroll
+    for (int k = -12; k <= 12; ++k) {
+      const int g1 = P[k + 4 + 16], g2 = P[k - 4 + 16];
+      if (g1 >= 0 && g2 >= 0 && g1 > g2) {
+        const long long wt = (long long)(g1 - g2) * (long long)(g1 - g2);
+        Mn += wt * k; Mc += wt;
+      }
+    }
+    double rx = 0.0, ry = 0.0, one = 0.0;
+    if (Mc != 0 && L > 0.0) {
+      const double n0 = ((double)Mn / (double)Mc) * 0.25;
+      const double ox = n0 * nx, oy = n0 * ny;
+      rx = tx + ox; ry = ty + oy; one = 1.0;
+    }
+    const double N = fid_tree16(one), Sx = fid_tree16(rx), Sy = fid_tree16(ry);
+    const double Sxx = fid_tree16(rx * rx), Sxy = fid_tree16(rx * ry), Syy = fid_tree16(ry * ry);
+    E[e][0] = ax; E[e][1] = ay; V[e][0] = nx; V[e][1] = ny;
+    if (N >= 4.0) {
+      const double Ex = Sx / N, Ey = Sy / N;
+      const double Cxx = Sxx / N - Ex * Ex, Cxy = Sxy / N - Ex * Ey, Cyy = Syy / N - Ey * Ey;
+      const double hd = (Cxx - Cyy) * 0.5;
+      const double r = sqrt(hd * hd + Cxy * Cxy);
+      double vx, vy;
+      if (hd >= 0.0) { vx = Cxy; vy = -hd - r; } else { vx = hd - r; vy = Cxy; }
+      const double vv = vx * vx + vy * vy;
+      if (vv > 1e-12) { E[e][0] = ax + Ex; E[e][1] = ay + Ey; V[e][0] = vx; V[e][1] = vy; }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int a = (c + 3) & 3, b = c;
+    const double cx = (double)qi[2 * c], cy = (double)qi[2 * c + 1];
+    const double ea = V[a][0] * (E[a][0] - cx) + V[a][1] * (E[a][1] - cy);
+    const double eb = V[b][0] * (E[b][0] - cx) + V[b][1] * (E[b][1] - cy);
+    const double det = V[a][0] * V[b][1] - V[a][1] * V[b][0];
+    const double na = V[a][0] * V[a][0] + V[a][1] * V[a][1], nb = V[b][0] * V[b][0] + V[b][1] * V[b][1];
+    double px = 0.0, py = 0.0;
+    bool ok = det * det > 1e-6 * (na * nb);
+    if (ok) {
+      px = (ea * V[b][1] - eb * V[a][1]) / det;
+      py = (V[a][0] * eb - V[b][0] * ea) / det;
+      ok = (px * px + py * py <= 16.0);
+    }
+    qr[2 * c] = ok ? cx + px : cx;
+    qr[2 * c + 1] = ok ? cy + py : cy;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ grey, int w, int h, int min_contrast,
                                                    const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
                                                    const double* __restrict__ pre_xy, int kstride,
                                                    const uint64_t* __restrict__ codes, int ncodes, int max_hamming,
-                                                   double tag_size, int max_targets,
+                                                   double tag_size, int max_targets, int refine_edges, double* __restrict__ ref_xy,
                                                    rcc_frame_corners* __restrict__ fc, rcc_detection* __restrict__ det,
                                                    int32_t* __restrict__ ndet)
 {
@@ -448,13 +557,29 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
       for (int c = 1; c < 4; ++c) { const int nx = have ? s_nxt[idx[c - 1]] : 0; idx[c] = nx; }
       double q[8];
       for (int c = 0; c < 4; ++c) { q[2 * c] = have ? xy[2 * idx[c]] : 0.0; q[2 * c + 1] = have ? xy[2 * idx[c] + 1] : 0.0; }
+      bool go = have;
+      if (refine_edges) {
+        // refine_edges form: the quad's corners come from its edges, started at the rounded positions the quad was found on
+        int qi[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qi[c] = (int)floor(q[c] + 0.5);
+        const long long cri = (long long)(qi[2] - qi[0]) * (qi[5] - qi[3]) - (long long)(qi[3] - qi[1]) * (qi[4] - qi[2]);
+        go = have && (cri > 0);
+        fid_refine_edges_group(g, w, h, qi, lg, go, q);
+        if (go && lg == 0) {
+          double* r = ref_xy + (size_t)f * kstride * 2;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { r[2 * idx[c]] = q[2 * c]; r[2 * idx[c] + 1] = q[2 * c + 1]; }
+        }
+      }
       const double e1 = (q[2] - q[0]) * (q[5] - q[3]), e2 = (q[3] - q[1]) * (q[4] - q[2]);
       const double cr = e1 - e2;
       int id = 0, ham = 0, rot = 0;
-      const bool hit = fid_decode_group<G>(g, w, h, q, codes, ncodes, max_hamming, lg, have && (cr > 0.0), id, ham, rot);
+      const bool hit = fid_decode_group<G>(g, w, h, q, codes, ncodes, max_hamming, lg, go && (cr > 0.0), id, ham, rot);
       if (hit && lg == 0) { fid_hit hrec; hrec.id = (int16_t)id; hrec.ham = (int8_t)ham; hrec.rot = (int8_t)rot; s_hit[i] = hrec; }
     }
   }
+  __threadfence_block();                   // the refined corners (global) are read back by this block's emission below
   __syncthreads();
   FID_TICK();
   // ordered emission (by the cycle's smallest index, as the specification's scan does): wave 0, one lane per hit
@@ -473,7 +598,8 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
         idx[0] = i; idx[1] = s_nxt[i]; idx[2] = s_nxt[idx[1]]; idx[3] = s_nxt[idx[2]];
         const int rot = hrec.rot;
         const int ord[4] = { (rot + 3) & 3, (rot + 2) & 3, (rot + 1) & 3, rot & 3 };   // bl, br, tr, tl
-        for (int c = 0; c < 4; ++c) { d.corners[c][0] = xy[2 * idx[ord[c]]]; d.corners[c][1] = xy[2 * idx[ord[c]] + 1]; }
+        const double* cxy = refine_edges ? ref_xy + (size_t)f * kstride * 2 : xy;     // (written by this block's decode stage, before the barrier)
+        for (int c = 0; c < 4; ++c) { d.corners[c][0] = cxy[2 * idx[ord[c]]]; d.corners[c][1] = cxy[2 * idx[ord[c]] + 1]; }
         for (int c = 0; c < 3; ++c) { d.rvec[c] = 0.0; d.tvec[c] = 0.0; }
         d.rms = 0.0; d.pnp_status = 0; d.pnp_iters = 0;
         det[(size_t)f * max_targets + m] = d;
@@ -533,7 +659,7 @@ hipError_t rcc_launch_fid(rcc_handle* h, const uint8_t* d_grey, int nframes, hip
   if (nframes <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_fid_quads, dim3(nframes), dim3(256), 0, s, d_grey, c.width, c.height, c.thr_min_contrast,
                      h->d_pre, h->d_npre, h->d_pre_xy, h->kept_cap, h->d_family, c.family_n, c.tag_max_hamming,
-                     c.tag_size, c.max_targets, h->d_fc, h->d_det, h->d_ndet);
+                     c.tag_size, c.max_targets, c.tag_refine == RCC_TAG_REFINE_EDGES ? 1 : 0, h->d_ref_xy, h->d_fc, h->d_det, h->d_ndet);
   return hipGetLastError();
 }
 

@@ -101,6 +101,7 @@ static int validate(const rcc_config* c)
     if (!c->family_codes || c->family_n < 1 || c->family_n > 65536 || !(c->tag_size > 0.0)) return RCC_ERR_ARG;
     if (c->tag_max_hamming < 0 || c->tag_max_hamming > 8 || c->max_targets > 4096) return RCC_ERR_ARG;
     if (c->max_kept > RCC_MAX_KEPT_FIDUCIAL) return RCC_ERR_ARG;
+    if (c->tag_refine != RCC_TAG_REFINE_EDGES && c->tag_refine != RCC_TAG_REFINE_CORNER_SUBPIX) return RCC_ERR_ARG;
   } else {
     return RCC_ERR_ARG;
   }
@@ -116,7 +117,7 @@ void rcc_destroy(rcc_handle* h)
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = { h->d_map, h->d_tilebox, h->d_flat, h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
-                   h->d_kept, h->d_kept_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
+                   h->d_kept, h->d_kept_xy, h->d_ref_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
                    h->d_board_obj, h->d_img_scratch, h->d_family, h->d_sp_tab };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_det) (void)hipHostFree(h->h_det);
@@ -162,6 +163,12 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->sp.win = cfg->subpix_win;
   h->sp.max_iter = cfg->subpix_max_iter;
   h->sp.eps2 = cfg->subpix_eps * cfg->subpix_eps;
+  if (cfg->target_kind == RCC_TARGET_FIDUCIAL && cfg->tag_refine == RCC_TAG_REFINE_EDGES) {
+    // refine_edges form: the a5 pass in front of the quad search is a coarse localisation (include/rcc.h)
+    if (h->sp.max_iter > RCC_TAG_COARSE_ITERS) h->sp.max_iter = RCC_TAG_COARSE_ITERS;
+    const double eps = cfg->subpix_eps > RCC_TAG_COARSE_EPS ? cfg->subpix_eps : RCC_TAG_COARSE_EPS;
+    h->sp.eps2 = eps * eps;
+  }
   for (int k = -cfg->subpix_win; k <= cfg->subpix_win; ++k) {
     double t = (double)k / (double)cfg->subpix_win;
     h->sp.m1[k + cfg->subpix_win] = exp(-(t * t));   // host libm, as the specification does
@@ -241,6 +248,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
     }
   }
   if (cfg->target_kind == RCC_TARGET_FIDUCIAL) {
+    ALLOC(h->d_ref_xy, B * (size_t)h->kept_cap * 2 * sizeof(double));
     ALLOC(h->d_family, (size_t)cfg->family_n * sizeof(uint64_t));
     if (hipMemcpy(h->d_family, cfg->family_codes, (size_t)cfg->family_n * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) {
       rcc_destroy(h);
@@ -449,6 +457,7 @@ static rcc_handle handle_view(const rcc_handle* h, int f0)
   v.d_thr += o * (size_t)((h->cfg.width + RCC_BAND_W - 1) / RCC_BAND_W) * (size_t)((h->cfg.height + 3) >> 2) * RCC_THR_PITCH;
   v.d_cand += o * (size_t)h->cfg.max_candidates; v.d_cand_count += o;
   v.d_pre += o * (size_t)h->kept_cap; v.d_npre += o; v.d_pre_xy += o * (size_t)h->kept_cap * 2;
+  if (v.d_ref_xy) v.d_ref_xy += o * (size_t)h->kept_cap * 2;
   v.d_kept += o * RCC_MAX_KEPT; v.d_kept_xy += o * RCC_MAX_KEPT * 2;
   v.d_fc += o; v.d_det += o * (size_t)h->cfg.max_targets; v.d_ndet += o;
   v.d_img_scratch += o * 2 * RCC_MAX_BOARD_CORNERS;

@@ -79,6 +79,7 @@ struct rcc_handle {
   rcc_cand* d_pre;        // B x 256
   int32_t* d_npre;        // B
   double* d_pre_xy;       // B x 256 x 2
+  double* d_ref_xy;       // fiducial handles: B x kept_cap x 2, refined corner of list entry i where it is a corner of a decoded quad (refine_edges form)
   rcc_cand* d_kept;       // B x 256 (validated, rounded refined pixel)
   double* d_kept_xy;      // B x 256 x 2
   rcc_frame_corners* d_fc;  // B

@@ -273,6 +273,59 @@ def render_tags(codes, placements, seed=11, noise=1.5, sigma=0.6):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8), np.array(corners)
 
 
+def refine_edges_np(grey, qi):
+    """The refine_edges form of the tag-corner refinement (DESIGN.md section 3, a5 for fiducials), written from the text with
+    whole-array machinery: every (edge, sample, offset) position at once by broadcasting, the fixed-point bilinear samples by
+    fancy indexing, the moments by np.sum, the line's normal from numpy's symmetric eigen-decomposition (LAPACK) and the
+    corners by np.linalg.solve -- where the oracle walks loops, sums along a pairing tree, takes the eigenvector in closed
+    form and intersects by Cramer's rule.  qi: 4 x 2 integer corners, clockwise on screen."""
+    g = grey.astype(np.int64)
+    h, w = g.shape
+    a = np.asarray(qi, float)                       # (4, 2)
+    b = np.roll(a, -1, axis=0)
+    d = b - a
+    L = np.hypot(d[:, 0], d[:, 1])
+    n = np.stack([d[:, 1] / L, -d[:, 0] / L], 1)    # outward normal
+    alpha = (np.arange(16) + 2) / 19.0
+    base = a[:, None, :] + alpha[None, :, None] * d[:, None, :]                     # (4, 16, 2)
+    j = np.arange(-16, 17) * 0.25
+    pos = base[:, :, None, :] + j[None, None, :, None] * n[:, None, None, :]        # (4, 16, 33, 2)
+    inside = (pos[..., 0] >= 0) & (pos[..., 1] >= 0) & (pos[..., 0] <= w - 2) & (pos[..., 1] <= h - 2)
+    X = np.rint(np.where(inside, pos[..., 0], 0.0) * 16.0).astype(np.int64)
+    Y = np.rint(np.where(inside, pos[..., 1], 0.0) * 16.0).astype(np.int64)
+    ix, iy, fx, fy = X >> 4, Y >> 4, X & 15, Y & 15
+    Pv = (16 - fx) * (16 - fy) * g[iy, ix] + fx * (16 - fy) * g[iy, ix + 1] + (16 - fx) * fy * g[iy + 1, ix] + fx * fy * g[iy + 1, ix + 1]
+    k = np.arange(-12, 13)
+    g1, g2 = Pv[:, :, k + 4 + 16], Pv[:, :, k - 4 + 16]
+    ok = inside[:, :, k + 4 + 16] & inside[:, :, k - 4 + 16] & (g1 > g2)
+    wt = np.where(ok, (g1 - g2) ** 2, 0)
+    Mc = wt.sum(-1)
+    Mn = (wt * k).sum(-1)
+    valid = Mc > 0
+    n0 = np.where(valid, Mn / np.where(valid, Mc, 1), 0.0) * 0.25
+    pts = (alpha[None, :, None] * d[:, None, :]) + n0[..., None] * n[:, None, :]    # relative to a
+    lines = []
+    for e in range(4):
+        p = pts[e][valid[e]]
+        if len(p) >= 4:
+            mu = p.mean(0)
+            C = (p - mu).T @ (p - mu) / len(p)
+            wv, V = np.linalg.eigh(C)
+            lines.append((a[e] + mu, V[:, 0]))           # normal = eigenvector of the smaller eigenvalue
+        else:
+            lines.append((a[e], n[e]))
+    out = np.zeros((4, 2))
+    for c in range(4):
+        (Ea, va), (Eb, vb) = lines[(c + 3) & 3], lines[c]
+        A = np.array([va, vb])
+        if abs(np.linalg.det(A)) ** 2 > 1e-6 * (va @ va) * (vb @ vb):
+            P_ = np.linalg.solve(A, np.array([va @ Ea, vb @ Eb]))
+            out[c] = P_ if np.sum((P_ - a[c]) ** 2) <= 16.0 else a[c]
+        else:
+            out[c] = a[c]
+    return out
+
+
 def main():
     views = [dict(seed=1, angle_deg=12.0, scale=21.0, tx=158.0, ty=121.0, persp=(0.012, -0.008), sigma=0.7, noise=1.5),
              dict(seed=2, angle_deg=-33.0, scale=17.5, tx=170.0, ty=112.0, persp=(-0.02, 0.015), sigma=1.0, noise=2.5),
@@ -306,6 +359,14 @@ def main():
              (21, 120.0, 330.0, 10.0, 270.0, (0.008, 0.008)), (34, 320.0, 320.0, 13.0, 37.0, (-0.01, 0.006)), (47, 520.0, 340.0, 9.5, -122.0, (0.0, 0.015))]
     fid_frame, fid_corners = render_tags(codes, place)
     out["fid_frame"] = fid_frame; out["fid_ids"] = np.array([p_[0] for p_ in place]); out["fid_corners"] = fid_corners
+    # refine_edges form: started from the true corners rounded to pixels and knocked off by up to 2 px (the quad search hands
+    # over positions of that quality), in the clockwise-on-screen order tl, tr, br, bl
+    knock = np.array([[[1, 0], [0, -1], [-1, 1], [0, 0]], [[0, 0], [2, 1], [0, -2], [-1, 0]], [[-1, -1], [0, 0], [1, 0], [0, 2]],
+                      [[0, 1], [-2, 0], [0, 0], [1, -1]], [[1, 1], [0, 0], [-1, 0], [0, -1]], [[0, 0], [0, 0], [0, 0], [0, 0]]])
+    fid_qi = np.rint(fid_corners[:, ::-1, :]).astype(np.int64) + knock
+    out["fid_qi"] = fid_qi
+    out["fid_refined"] = np.stack([refine_edges_np(fid_frame, q) for q in fid_qi])
+    print("refine_edges (numpy) vs the drawn corners: max |err| per tag", np.abs(out["fid_refined"] - fid_corners[:, ::-1, :]).max(axis=(1, 2)).round(3))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "image_xcheck.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; candidates", out["cand_n"], "suppressed", out["pre_n"],
