@@ -594,16 +594,58 @@ def main():
             hostf = torch.empty((B, cfg.frame_bytes), dtype=torch.uint8, pin_memory=True)
             hostf.copy_(frames)
             torch.cuda.synchronize()
-            det.detect(hostf, B, want_corners=False)
-            reps = 2
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                det.detect(hostf, B, want_corners=False)
-            dth = (time.perf_counter() - t1) / reps
-            out["value_with_h2d"] = {"value": B / dth, "unit": "frames/s", "ms_per_step": 1e3 * dth,
-                                     "what": "the same step with the batch in pinned HOST memory (RCC_MEM_HOST): one hipMemcpyAsync of the batch, then the kernels",
+
+            def timed(fn, reps=5):
+                fn()
+                ts = []
+                for _ in range(reps):
+                    t1 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t1)
+                return statistics.median(ts), ts
+            # what the link itself delivers for these bytes: the batch copied in 64-MiB pieces on two streams, nothing else
+            dstb = torch.empty_like(frames)
+            cs = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+            flat_h, flat_d = hostf.view(-1), dstb.view(-1)
+
+            def copy_only():
+                step = 64 << 20
+                for k, o in enumerate(range(0, flat_h.numel(), step)):
+                    with torch.cuda.stream(cs[k & 1]):
+                        flat_d[o:o + step].copy_(flat_h[o:o + step], non_blocking=True)
+                torch.cuda.synchronize()
+            t_copy, _ = timed(copy_only)
+            del dstb
+            det.set_host_chunk(0)
+            dth, all_p = timed(lambda: det.detect(hostf, B, want_corners=False))
+            det.set_host_chunk(-1)
+            dth1, _ = timed(lambda: det.detect(hostf, B, want_corners=False), 3)
+            det.set_host_chunk(0)
+            link = B * cfg.frame_bytes / t_copy / 1e9
+            out["value_with_h2d"] = {"value": B / dth, "unit": "frames/s", "ms_per_step": 1e3 * dth, "repetitions": len(all_p), "all_ms": [1e3 * t for t in all_p],
+                                     "what": "the same step with the batch in pinned HOST memory (RCC_MEM_HOST): chunks of ~192 MiB copied on two streams, each chunk's kernels under the next chunks' copies (median of 5)",
                                      "h2d_GBps": B * cfg.frame_bytes / dth / 1e9,
+                                     "one_copy_then_kernels": {"value": B / dth1, "ms_per_step": 1e3 * dth1, "what": "rounds 1-2: one hipMemcpyAsync of the batch, then the kernels"},
+                                     "link_measured_GBps": link, "link_measured_frames_per_s": link * 1e9 / cfg.frame_bytes,
+                                     "link_measured_what": "the same bytes copied host -> device in 64-MiB pieces on two streams, no kernels (median of 5): what the PCIe path of this box delivers",
+                                     "frac_of_measured_link": (B / dth) / (link * 1e9 / cfg.frame_bytes),
                                      "pcie_ceiling_frames_per_s": PCIE_GBS * 1e9 / cfg.frame_bytes, "pcie_GBps_spec": PCIE_GBS}
+            # the same with MONO8 frames (1/3 of the bytes per frame): the grey planes of the batch as host input
+            try:
+                cfgm = api.clone_config(cfg)
+                abi.set_geometry(cfgm, a.width, a.height, abi.RCC_PIX_MONO8)
+                for i in range(9):
+                    cfgm.K[i] = cfg.K[i]
+                detm = api.Detector(cfgm)
+                hostm = torch.empty((B, cfgm.frame_bytes), dtype=torch.uint8, pin_memory=True)
+                hostm.copy_(frames.view(B, -1, 3)[:, :, 1])            # the green plane: a mono rendition of the same scenes
+                torch.cuda.synchronize()
+                dm, _ = detm.detect(hostm, B, want_corners=False)
+                dtm, _ = timed(lambda: detm.detect(hostm, B, want_corners=False))
+                out["value_with_h2d"]["mono8"] = {"value": B / dtm, "unit": "frames/s", "ms_per_step": 1e3 * dtm, "h2d_GBps": B * cfgm.frame_bytes / dtm / 1e9,
+                                                  "targets_found": len(dm), "what": "the same scenes as MONO8 frames in pinned host memory (2.07 MB per frame)"}
+                detm.close()
+                del hostm
+            except Exception as e:
+                out["value_with_h2d"]["mono8"] = {"error": repr(e)}
             del hostf
             cfg1 = api.clone_config(cfg)
             cfg1.batch_capacity = 1

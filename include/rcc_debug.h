@@ -39,6 +39,10 @@ int rcc_set_fuse_grid_pnp(rcc_handle* h, int on);
 /* n > 1: cut each batch into n chunks (>= 64 frames) alternating over two internal streams; default 1 (a single pass is
  * faster at every size measured on MI355X: DESIGN.md section 5).  Per-stage timings exist only for n <= 1. */
 int rcc_set_pipeline(rcc_handle* h, int nchunks);
+/* host-resident batches (RCC_MEM_HOST) go over as a pipeline of chunks, each chunk's kernels under the next chunks' copies:
+ * frames per chunk (0 = automatic, about 192 MiB; < 0 = one copy of the whole batch, then the kernels -- the A/B form).
+ * Same records either way.  Returns the previous setting. */
+int rcc_set_host_chunk(rcc_handle* h, int frames_per_chunk);
 /* PnP mapping: 0 = one lane per target, 1 = one wavefront per target with more than 8 points, -1 = automatic (= 1) */
 int rcc_set_pnp_variant(rcc_handle* h, int variant);
 

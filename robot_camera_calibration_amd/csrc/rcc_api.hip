@@ -130,6 +130,7 @@ void rcc_destroy(rcc_handle* h)
   if (h->stream) (void)hipStreamDestroy(h->stream);
   for (auto& ps : h->pstream) if (ps) (void)hipStreamDestroy(ps);
   for (auto& e : h->pev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->cev) if (e) (void)hipEventDestroy(e);
   delete h;
 }
 
@@ -477,6 +478,70 @@ int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, cons
                      (const int32_t*)d_cand_count, nframes, det, ndet, corners, s);
 }
 
+// the staging buffer for host-resident input (sized for batch_capacity once)
+static int ensure_stage(rcc_handle* h, size_t need, bool may_realloc)
+{
+  if (need <= h->stage_bytes) return RCC_OK;
+  if (!may_realloc) return RCC_ERR_STATE;          // cannot re-allocate the staging buffer under a batch in flight
+  if (h->d_stage) (void)hipFree(h->d_stage);
+  h->d_stage = nullptr;
+  h->stage_bytes = 0;
+  const size_t cap = (size_t)h->cfg.frame_bytes * h->cfg.batch_capacity;
+  if (hipMalloc((void**)&h->d_stage, cap) != hipSuccess) return RCC_ERR_NOMEM;
+  h->stage_bytes = cap;
+  return RCC_OK;
+}
+
+// Frames per chunk of the host-input pipeline, or 0 when the batch goes over in one copy.  The copy engine is fastest on
+// transfers of 64-256 MiB (one 6-GB copy: 50-55 GB/s; chunks: 56-57 GB/s, scratch/t_h2d.py), and every chunk's kernels
+// run under the following chunks' copies, so only the last chunk's kernels are exposed: chunks of about 192 MiB, at
+// most RCC_HOST_CHUNKS of them, and at least 8 frames each (the tail stages are a fixed-length chain per launch).
+static int host_chunk_frames(const rcc_handle* h, int nframes)
+{
+  if (h->host_chunk_frames < 0) return 0;
+  long long per = h->host_chunk_frames > 0 ? h->host_chunk_frames : (long long)((192ull << 20) / (unsigned long long)h->cfg.frame_bytes);
+  if (per < 8) per = 8;
+  if ((nframes + per - 1) / per > RCC_HOST_CHUNKS) per = (nframes + RCC_HOST_CHUNKS - 1) / RCC_HOST_CHUNKS;
+  return nframes >= 2 * per ? (int)per : 0;
+}
+
+// Host-resident batch as a pipeline: chunk c is copied on one of two copy streams (alternating: the next copy is queued
+// while this one runs) and its kernels -- ingest, threshold + corner pass, targets, over the chunk's slices of the
+// handle's buffers -- follow on the caller's stream s as soon as the copy has landed, under the copies of the chunks
+// behind it.  Same records as the one-copy form (chunks only touch their own frames' slices).
+static int launch_host_pipeline(rcc_handle* h, const uint8_t* host_frames, int nframes, int per, hipStream_t s)
+{
+  const size_t fb = (size_t)h->cfg.frame_bytes;
+  const int nchunks = (nframes + per - 1) / per;
+  // the staging buffer and the per-frame buffers are this handle's only set: the copies wait for everything queued on s
+  HIPCHK(h, hipEventRecord(h->pev[0], s));
+  for (int k = 0; k < 2; ++k) HIPCHK(h, hipStreamWaitEvent(h->pstream[k], h->pev[0], 0));
+  for (int c = 0; c < nchunks; ++c) {
+    const int f0 = c * per, f1 = (f0 + per < nframes) ? f0 + per : nframes;
+    if (!h->cev[c]) HIPCHK(h, hipEventCreateWithFlags(&h->cev[c], hipEventDisableTiming));
+    hipStream_t cs = h->pstream[c & 1];
+    HIPCHK(h, hipMemcpyAsync(h->d_stage + (size_t)f0 * fb, host_frames + (size_t)f0 * fb, (size_t)(f1 - f0) * fb, hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipEventRecord(h->cev[c], cs));
+  }
+  for (int c = 0; c < nchunks; ++c) {
+    const int f0 = c * per, f1 = (f0 + per < nframes) ? f0 + per : nframes;
+    HIPCHK(h, hipStreamWaitEvent(s, h->cev[c], 0));
+    rcc_handle v = handle_view(h, f0);
+    v.want_thr = h->keep_bin ? 0 : 1;
+    if (v.dense_variant == 3) v.dense_variant = 1;      // (one flat-mask buffer per handle: see the chunked device path)
+    hipError_t e = rcc_launch_ingest(&v, h->d_stage + (size_t)f0 * fb, f1 - f0, v.d_grey, s);
+    h->d_map = v.d_map; h->d_tilebox = v.d_tilebox; h->map_failed = v.map_failed;     // tables built by the first launch belong to the handle
+    if (e == hipSuccess) e = rcc_launch_dense(&v, v.d_grey, f1 - f0, v.d_bin, v.d_cand, v.d_cand_count, s);
+    if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s", hipGetErrorString(e)); return RCC_ERR_DEVICE; }
+    h->dense_kernel = v.dense_kernel;
+    int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, s, false);
+    if (r != RCC_OK) { snprintf(h->err, sizeof(h->err), "%s", v.err); return r; }
+    h->bin_from_thr = v.bin_from_thr;
+  }
+  for (float& m : h->last_ms) m = -1.0f;               // stages of different chunks overlap the copies: no separate durations
+  return RCC_OK;
+}
+
 int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t frames_mem,
                      rcc_detection* det, int32_t* ndet, rcc_frame_corners* corners, void* stream)
 {
@@ -491,16 +556,15 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const uint8_t* d_frames = (const uint8_t*)frames;
   if (frames_mem == RCC_MEM_HOST) {
-    size_t need = (size_t)h->cfg.frame_bytes * nframes;
-    if (need > h->stage_bytes) {
-      if (h->d_stage) (void)hipFree(h->d_stage);
-      h->d_stage = nullptr;
-      h->stage_bytes = 0;
-      size_t cap = (size_t)h->cfg.frame_bytes * h->cfg.batch_capacity;
-      if (hipMalloc((void**)&h->d_stage, cap) != hipSuccess) return RCC_ERR_NOMEM;
-      h->stage_bytes = cap;
+    { int rs = ensure_stage(h, (size_t)h->cfg.frame_bytes * nframes, true); if (rs != RCC_OK) return rs; }
+    const int per = host_chunk_frames(h, nframes);
+    if (per > 0) {
+      int r = launch_host_pipeline(h, (const uint8_t*)frames, nframes, per, s);
+      if (r != RCC_OK) return r;
+      if (h->rec_table[0]) HIPCHK(h, rcc_launch_pack_records(h, nframes, h->rec_offset, h->rec_table[0], s));
+      return collect_targets(h, nframes, det, ndet, corners, s, false);
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_stage, frames, need, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_stage, frames, (size_t)h->cfg.frame_bytes * nframes, hipMemcpyHostToDevice, s));
     d_frames = h->d_stage;
   }
   // Pipeline: the batch is cut into chunks that alternate over two streams, so that the latency-bound tail of
@@ -573,30 +637,34 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   if (detect_needs_bin(h)) { int rb = ensure_bin(h); if (rb != RCC_OK) return rb; }
   const int slot = (int)(h->sub_head & 1u);
   const uint8_t* d_frames = (const uint8_t*)frames;
+  bool piped = false;
   if (frames_mem == RCC_MEM_HOST) {
-    size_t need = (size_t)h->cfg.frame_bytes * nframes;
-    if (need > h->stage_bytes) {
-      if (h->sub_head != h->sub_tail) return RCC_ERR_STATE;          // cannot re-allocate the staging buffer under a batch in flight
-      if (h->d_stage) (void)hipFree(h->d_stage);
-      h->d_stage = nullptr;
-      h->stage_bytes = 0;
-      size_t cap = (size_t)h->cfg.frame_bytes * h->cfg.batch_capacity;
-      if (hipMalloc((void**)&h->d_stage, cap) != hipSuccess) return RCC_ERR_NOMEM;
-      h->stage_bytes = cap;
+    { int rs = ensure_stage(h, (size_t)h->cfg.frame_bytes * nframes, h->sub_head == h->sub_tail); if (rs != RCC_OK) return rs; }
+    const int per = host_chunk_frames(h, nframes);
+    if (per > 0) {
+      int r = launch_host_pipeline(h, (const uint8_t*)frames, nframes, per, s);
+      if (r != RCC_OK) return r;
+      piped = true;
+    } else {
+      HIPCHK(h, hipMemcpyAsync(h->d_stage, frames, (size_t)h->cfg.frame_bytes * nframes, hipMemcpyHostToDevice, s));
+      d_frames = h->d_stage;
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_stage, frames, need, hipMemcpyHostToDevice, s));
-    d_frames = h->d_stage;
   }
   const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
   const int slots = h->cfg.max_targets;
-  HIPCHK(h, rcc_launch_ingest(h, d_frames, nframes, h->d_grey, s));
-  h->want_thr = h->keep_bin ? 0 : 1;
-  HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][0], s));
-  HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
-  HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][1], s));
-  h->want_thr = 0;
-  int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, false);
-  if (r != RCC_OK) return r;
+  if (piped) {
+    HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][0], s));       // (no separate duration for the pass in this form)
+    HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][1], s));
+  } else {
+    HIPCHK(h, rcc_launch_ingest(h, d_frames, nframes, h->d_grey, s));
+    h->want_thr = h->keep_bin ? 0 : 1;
+    HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][0], s));
+    HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
+    HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][1], s));
+    h->want_thr = 0;
+    int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, false);
+    if (r != RCC_OK) return r;
+  }
   if (h->rec_table[slot]) HIPCHK(h, rcc_launch_pack_records(h, nframes, h->rec_offset, h->rec_table[slot], s));
   rcc_detection* hd = slot ? h->h_det2 : h->h_det;
   int32_t* hn = slot ? h->h_ndet2 : h->h_ndet;
@@ -673,6 +741,16 @@ int rcc_set_keep_binary(rcc_handle* h, int on)
   if (!h) return RCC_ERR_ARG;
   int p = h->keep_bin;
   h->keep_bin = on ? 1 : 0;
+  return p;
+}
+
+// host-resident batches: frames per chunk of the copy / compute pipeline (0 automatic, < 0 one copy then the kernels);
+// returns the previous setting
+int rcc_set_host_chunk(rcc_handle* h, int frames_per_chunk)
+{
+  if (!h) return RCC_ERR_ARG;
+  const int p = h->host_chunk_frames;
+  h->host_chunk_frames = frames_per_chunk;
   return p;
 }
 

@@ -10,6 +10,7 @@
 #define RCC_MAX_KEPT 256
 #define RCC_THR_PITCH 512     // bytes per tile row of one band in the compact threshold map (480 used at 1920 columns)
 #define RCC_BAND_W 1920        // output columns per band of the band kernel
+#define RCC_HOST_CHUNKS 64      // at most this many chunks per host-resident batch
 
 // Flat masks of the two-kernel threshold + corner pass (k_dense_band.hip sweep -> k_dense_runs.hip): one 64-bit word per
 // (frame, band, window of the band, tile row): bit l = lane l's 4x4 tile has a dilated contrast below min_contrast.
@@ -107,6 +108,8 @@ struct rcc_handle {
   float last_ms[5];
   hipStream_t pstream[2];   // chunk streams of rcc_detect_batch's pipeline
   hipEvent_t pev[3];        // [0] input ready on the caller's stream, [1..2] chunk streams drained
+  hipEvent_t cev[RCC_HOST_CHUNKS];   // host-input pipeline: chunk c's copy has landed in the staging buffer (created on first use)
+  int host_chunk_frames;    // 0: automatic (about 192 MiB per chunk); > 0: frames per chunk; < 0: one copy of the whole batch, then the kernels
   int pipeline_chunks;      // 0/1: one pass over the whole batch on one stream; n > 1: n chunks alternating over two streams
   int dense_variant, ingest_variant;
   int dense_skip;           // 1: the fast dense kernel may skip flat wave-rows (exact); 0: never (A/B, tests)

@@ -556,6 +556,37 @@ def test_pipeline_chunks_identical(torch_cuda):
     det.close()
 
 
+def test_host_input_pipeline_identical(torch_cuda):
+    """RCC_MEM_HOST batches go over as a pipeline of chunks (copies on two streams, each chunk's kernels under the next
+    chunks' copies): the records and corner tables equal those of the one-copy form and of device-resident input, for
+    detect() and for submit / collect, ragged last chunk included"""
+    torch = torch_cuda
+    n = 100
+    cfg = _make(w=640, h=480, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch, det, cfg, n, seed=777)
+    frames[17].zero_()                                       # a frame without a board in the middle of a chunk
+    torch.cuda.synchronize()
+    host = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, pin_memory=True)
+    host.copy_(frames); torch.cuda.synchronize()
+    d_dev, f_dev = det.detect(frames, n)
+    det.set_host_chunk(-1)
+    d_one, f_one = det.detect(host, n)
+    outs = []
+    for per in (8, 13, 64):                                  # 13 chunks (last one of 4 frames), 8 chunks (last of 9), 2 chunks (64 + 36)
+        det.set_host_chunk(per)
+        outs.append(det.detect(host, n))
+        det.submit(host, n, want_corners=True); det.submit(host, n, want_corners=True)
+        outs.append(det.collect()); outs.append(det.collect())
+    det.set_host_chunk(0)
+    outs.append(det.detect(host.numpy(), n))                 # pageable numpy memory takes the same path
+    assert len(d_dev) >= n - 3 and 17 not in set(d_dev.frame.tolist())
+    assert d_one.tobytes() == d_dev.tobytes() and f_one.tobytes() == f_dev.tobytes()
+    for d, f in outs:
+        assert d.tobytes() == d_dev.tobytes() and f.tobytes() == f_dev.tobytes()
+    det.close()
+
+
 def test_full_size_properties(torch_cuda):
     """1920x1080 (BASELINE.json's size), no oracle: size-independent properties of the path --
     idempotence (same frames twice -> identical records), batch-order independence (a frame's
