@@ -556,12 +556,36 @@ def main():
                 except Exception:
                     pass
             return None, "none"
+        props = torch.cuda.get_device_properties(dev)
+        simds = int(props.multi_processor_count) * 4
+        clock_mhz = float(getattr(props, "clock_rate", 2400000)) / 1e3
+        VALU_CYCLES = 4.4      # cycles per wave64 vector instruction per SIMD for this instruction mix at 6 waves per SIMD (profiles/r02_vbench.txt, r02_vbench_ilp.txt)
+
+        def issue_of(name, ms_launch):
+            """the vector-issue roofline of the pass: SQ instruction counts of a committed profile x the measured issue cost"""
+            ipath = os.path.join(ROOT, "profiles", name)
+            if not (os.path.exists(ipath) and (a.width, a.height) == (1920, 1080) and not a.fisheye and not fid):
+                return None
+            try:
+                j = json.load(open(ipath))
+                valu, salu = float(j["valu_wave_insts_per_frame"]), float(j["salu_wave_insts_per_frame"])
+                bound_ms = valu * B * VALU_CYCLES / (simds * clock_mhz * 1e6) * 1e3
+                return {"valu_wave_insts_per_frame": valu, "salu_wave_insts_per_frame": salu, "cycles_per_inst": VALU_CYCLES,
+                        "cycles_per_inst_source": "profiles/r02_vbench.txt, r02_vbench_ilp.txt: packed 16-bit / dot2 / DPP / perm / compare classes at 6 waves per SIMD",
+                        "simds": simds, "clock_mhz": clock_mhz, "issue_bound_ms": bound_ms, "frac_of_issue_bound": bound_ms / ms_launch,
+                        "source": "profiles/%s <- profiles/%s: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU of %s on an earlier run of this code, scaled per frame; not measured in this run" % (name, j.get("source"), j.get("kernel"))}
+            except Exception:
+                return None
         tr_c, src_c = traffic_of("traffic_dense_step.json")
         tr_s, src_s = traffic_of("traffic_dense.json")
         # yardstick measured in the same process: a plain streaming copy of the same bytes (grey -> binary buffer)
         copy_ms = det.time_copy(grey, binm, B * px, a.roofline_reps) if (B * px) % 16 == 0 else None
+        iss_c, iss_s = issue_of("issue_dense_step.json", ms_c), issue_of("issue_dense.json", ms)
+        hbm_frac_traffic = (tr_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr_c else (algc / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS)
+        bound = "valu-issue" if (iss_c and iss_c["frac_of_issue_bound"] > hbm_frac_traffic) else "hbm"
         out["roofline"] = {
-            "bound": "hbm", "kernel": k_step, "kernel_in_timed_step": step_dense_kernel,
+            "bound": bound, "bound_what": "the resource the kernel runs closest to: vector-instruction issue (roofline.issue) vs HBM (achieved / peak / frac below are the HBM figures on algorithmic bytes, as BASELINE.json's metric asks; frac_hbm_on_traffic counts the bytes the counters saw)",
+            "frac_hbm_on_traffic": hbm_frac_traffic, "issue": iss_c, "kernel": k_step, "kernel_in_timed_step": step_dense_kernel,
             "what": "threshold+corner pass as rcc_detect_batch launches it (binary image kept as a 1-byte-per-4x4-tile threshold map)",
             "achieved": algc / (ms_c * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": algc / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_2px": alg2 / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -569,8 +593,7 @@ def main():
             "ms_per_launch_source": ("HIP events around the launch inside each of the %d timed steps (mean)" % len(dense_in_step)) if dense_in_step and min(dense_in_step) > 0 else "back-to-back launches (no in-step events in this mode)",
             "ms_per_launch_back_to_back": ms_b2b, "frac_back_to_back": algc / (ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_2px_back_to_back": alg2 / (ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": tr_c, "traffic_source": src_c,
-            "limiter": "vector-instruction issue, not HBM: see DESIGN.md section 5 (profiles/r02_vbench.txt, r02_*_sq_dense.txt)",
-            "stage_form": {"kernel": k_stage, "what": "the same pass writing the full binary image (rcc_stage_threshold_corner), 2*px algorithmic bytes per frame",
+            "stage_form": {"kernel": k_stage, "issue": iss_s, "what": "the same pass writing the full binary image (rcc_stage_threshold_corner), 2*px algorithmic bytes per frame",
                            "ms_per_launch": ms, "alg_bytes_per_launch": alg2, "achieved": alg2 / (ms * 1e-3) / 1e9,
                            "frac": alg2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_of_guide_copy_6290": alg2 / (ms * 1e-3) / 1e9 / 6290.0,
                            "traffic": tr_s, "traffic_source": src_s,

@@ -21,7 +21,9 @@ cd $R
 python3 scripts/summarize_pmc.py $O/dense_FETCH_SIZE/p_counter_collection.csv $O/dense_WRITE_SIZE/p_counter_collection.csv 512 $TAG "k_dense_band<0" 4147200 k_calib_copy_x4 dense > $O/dense_traffic.txt
 python3 scripts/summarize_pmc.py $O/dense_FETCH_SIZE/p_counter_collection.csv $O/dense_WRITE_SIZE/p_counter_collection.csv 512 $TAG k_dense_wave 2203200 k_calib_copy_x4 dense_step > $O/dense_step_traffic.txt
 python3 scripts/summarize_pmc.py $O/ingest_FETCH_SIZE/p_counter_collection.csv $O/ingest_WRITE_SIZE/p_counter_collection.csv 256 $TAG k_ingest_staged 8294400 > $O/ingest_traffic.txt
+python3 scripts/summarize_sq.py $O/dense_sq1 512 $TAG "k_dense_band<0" dense > $O/issue_dense.txt
+python3 scripts/summarize_sq.py $O/dense_sq1 512 $TAG k_dense_wave dense_step > $O/issue_dense_step.txt
 python3 scripts/pmc_table.py $O/dense_sq1 k_dense > $O/dense_sq.txt
 python3 scripts/pmc_table.py $O/dense_sq2 k_dense >> $O/dense_sq.txt
-cp profiles/${TAG}_pmc_dense.json profiles/${TAG}_pmc_dense_step.json profiles/${TAG}_pmc_ingest.json profiles/traffic_dense.json profiles/traffic_dense_step.json profiles/traffic_ingest.json $O/ 2>/dev/null || true
+cp profiles/${TAG}_pmc_dense.json profiles/${TAG}_pmc_dense_step.json profiles/${TAG}_pmc_ingest.json profiles/traffic_dense.json profiles/traffic_dense_step.json profiles/traffic_ingest.json profiles/issue_dense.json profiles/issue_dense_step.json $O/ 2>/dev/null || true
 tail -1 $O/bench.json
