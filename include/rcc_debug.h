@@ -38,6 +38,10 @@ int rcc_set_dense_skip(rcc_handle* h, int on);
 int rcc_set_fuse_grid_pnp(rcc_handle* h, int on);
 /* n > 1: cut each batch into n chunks (>= 64 frames) alternating over two internal streams; default 1 (a single pass is
  * faster at every size measured on MI355X: DESIGN.md section 5).  Per-stage timings exist only for n <= 1. */
+/* k_dense_wave (the step's threshold + corner kernel) as gangs of eight windows per workgroup that meet at a barrier every
+ * sync_rows tile rows (a power of two; 0 = every window on its own); segments per frame for that form (0 = default).
+ * Bit-identical outputs.  Returns the previous sync_rows. */
+int rcc_set_dense_gang(rcc_handle* h, int sync_rows, int segments);
 int rcc_set_pipeline(rcc_handle* h, int nchunks);
 /* host-resident batches (RCC_MEM_HOST) go over as a pipeline of chunks, each chunk's kernels under the next chunks' copies:
  * frames per chunk (0 = automatic, about 192 MiB; < 0 = one copy of the whole batch, then the kernels -- the A/B form).

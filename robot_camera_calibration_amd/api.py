@@ -89,6 +89,8 @@ def load_library():
     L.rcc_set_fuse_grid_pnp.restype = C.c_int
     L.rcc_set_keep_binary.argtypes = [P, C.c_int]
     L.rcc_set_keep_binary.restype = C.c_int
+    L.rcc_set_dense_gang.argtypes = [P, C.c_int, C.c_int]
+    L.rcc_set_dense_gang.restype = C.c_int
     L.rcc_set_host_chunk.argtypes = [P, C.c_int]
     L.rcc_set_host_chunk.restype = C.c_int
     L.rcc_set_pipeline.argtypes = [P, C.c_int]
@@ -131,7 +133,7 @@ EXPORTED_SYMBOLS = (
 )
 # include/rcc_debug.h: test taps, timers, A/B switches between bit-identical variants (not part of the boundary)
 DEBUG_EXPORTED_SYMBOLS = (
-    "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_set_dense_skip", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline", "rcc_set_host_chunk",
+    "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_set_dense_skip", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline", "rcc_set_host_chunk", "rcc_set_dense_gang",
     "rcc_set_pnp_variant", "rcc_last_timings", "rcc_last_dense_kernel", "rcc_time_dense", "rcc_time_ingest", "rcc_time_copy",
     "rcc_debug_calib_copy", "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_debug_pnp_probe",
 )
@@ -375,6 +377,9 @@ class Detector:
     def set_pipeline(self, nchunks):
         """chunks of detect()'s two-stream pipeline (0/1: single pass, per-stage timings available)"""
         return self._L.rcc_set_pipeline(self._h, int(nchunks))
+
+    def set_dense_gang(self, sync_rows, segments=0):
+        return self._L.rcc_set_dense_gang(self._h, int(sync_rows), int(segments))
 
     def set_host_chunk(self, frames_per_chunk):
         """host-resident input: frames per chunk of the copy / compute pipeline (0 automatic, < 0 one copy then the kernels)"""

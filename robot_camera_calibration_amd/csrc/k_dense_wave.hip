@@ -33,22 +33,34 @@
 #define WAVE_PRIO 0           // s_setprio around the corner stages: independent waves have nobody to get ahead of (measured the same with 1)
 #endif
 
-template <int PRIO>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6)))
+// GANG = 1: every window is a workgroup of its own (the form described above, what the product launches).  GANG = 8
+// (rcc_set_dense_gang, measurement only): the eight windows of a band segment are the eight wavefronts of ONE workgroup --
+// still no shared rows, no per-row barrier, each wave with its own ring -- but every `syncmask + 1` tile rows the gang
+// meets at a barrier, so that no wave runs far ahead of its neighbours: the 64-byte sectors two neighbouring windows share
+// (a 256-byte fetch every 244 bytes touches five) are then still cached when the second window asks for them.  Measured on
+// 1024 x 1080p: HBM traffic 1.09 x the algorithmic bytes instead of 1.48 x, and 0.83-0.87 ms instead of 0.70 ms (gangs of 2
+// and 4 windows: 0.91 / 0.83 ms) -- the pass is bound by vector-instruction issue, not by its fetches, and the free-running
+// windows keep the SIMDs evenly loaded; so the re-reads stay (profiles/r03_e_pmc_dense_gang.json).
+template <int PRIO, int GANG>
+__global__ __launch_bounds__(64 * GANG) __attribute__((amdgpu_waves_per_eu(6, 6)))
 void k_dense_wave(const uint8_t* __restrict__ grey, int w, int h, int nbands, int nwin, int nseg, int seg_tiles, int nframes,
                   int min_contrast, int hthresh, int margin, int cap, int allow_skip, uint8_t* __restrict__ thr_map,
-                  rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count, int fchunk)
+                  rcc_cand* __restrict__ cand, int32_t* __restrict__ cand_count, int fchunk, int syncmask)
 {
-  __shared__ __attribute__((aligned(1024))) uint8_t ring[WAVE_RING * 1024];
+  __shared__ __attribute__((aligned(1024))) uint8_t ring_all[GANG * WAVE_RING * 1024];
   // workgroup -> job, as the band kernel deals them (an XCD takes chunks of consecutive frames along a diagonal); the
   // windows of a band segment are consecutive jobs of one XCD, so the halo columns they share meet in its L2
-  const int jpf = nbands * nseg * nwin, cj = fchunk * jpf, k = (int)(blockIdx.x >> 3);
+  const int wpj = (GANG > 1) ? 1 : nwin;                       // jobs (workgroups) per band segment
+  const int jpf = nbands * nseg * wpj, cj = fchunk * jpf, k = (int)(blockIdx.x >> 3);
   const int grp = k / cj, r = k - grp * cj;
   const int f = (8 * grp + (((int)(blockIdx.x & 7u) - grp) & 7)) * fchunk + r / jpf;
   if (f >= nframes) return;
   const int jr = r % jpf;
-  const int wv = jr % nwin, band = (jr / nwin) % nbands, seg = jr / (nwin * nbands);
-  const int lane = threadIdx.x;
+  const int wv = (GANG > 1) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : jr % wpj;
+  const int band = (jr / wpj) % nbands, seg = jr / (wpj * nbands);
+  if (GANG > 1 && wv >= nwin) return;
+  uint8_t* const ring = ring_all + (GANG > 1 ? wv * (WAVE_RING * 1024) : 0);
+  const int lane = threadIdx.x & 63;
   const int th = h >> 2;
   const int t0 = seg * seg_tiles;
   const int t1 = min(t0 + seg_tiles, th);
@@ -107,6 +119,7 @@ void k_dense_wave(const uint8_t* __restrict__ grey, int w, int h, int nbands, in
 
   auto do_tile = [&](const int t, const TStat& ha, const TStat& hb, TStat& hn,
                      const mask64 Fa, const mask64 Fb, mask64& Fn, SobelRow& sa, SobelRow& sb, SobelRow& sc) {
+    if (GANG > 1 && ((t - t0) & syncmask) == 0) __builtin_amdgcn_s_barrier();     // the gang's meeting point (data-wise nothing depends on it)
     // tile row t has landed: the DMA that fetched it has 2 * WAVE_DEPTH - 1 younger operations of this wave
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * WAVE_DEPTH - 1) : "memory");
     const int sd = (sf + WAVE_DEPTH >= WAVE_RING) ? sf + WAVE_DEPTH - WAVE_RING : sf + WAVE_DEPTH;
@@ -183,10 +196,22 @@ hipError_t rcc_launch_dense_wave(rcc_handle* h, const uint8_t* d_grey, int nfram
   if (nseg < 1) nseg = 1;
   const int seg_tiles = (th + nseg - 1) / nseg;
   nseg = (th + seg_tiles - 1) / seg_tiles;
+  if (h->dense_gang_sync > 0 && nwin <= 8) {
+    // the gang form (measurement only): one workgroup of eight wavefronts per band segment
+    int gs = h->dense_gang_seg > 0 ? h->dense_gang_seg : nseg;
+    const int gst = (th + gs - 1) / gs;
+    gs = (th + gst - 1) / gst;
+    const long long nj = (long long)nbands * gs * ((nframes + 8 * fchunk - 1) / (8 * fchunk)) * 8 * fchunk;
+    h->dense_kernel = "k_dense_wave<0, 8>";
+    hipLaunchKernelGGL((k_dense_wave<WAVE_PRIO, 8>), dim3((unsigned)nj), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nwin, gs, gst,
+                       nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, rcc_dense_allow_skip(h), h->d_thr,
+                       d_cand, d_cand_count, fchunk, h->dense_gang_sync - 1);
+    return hipGetLastError();
+  }
   const long long njobs = (long long)nbands * nseg * nwin * ((nframes + 8 * fchunk - 1) / (8 * fchunk)) * 8 * fchunk;
-  h->dense_kernel = "k_dense_wave<0>";
-  hipLaunchKernelGGL((k_dense_wave<WAVE_PRIO>), dim3((unsigned)njobs), dim3(64), 0, s, d_grey, c.width, c.height, nbands, nwin, nseg, seg_tiles,
+  h->dense_kernel = "k_dense_wave<0, 1>";
+  hipLaunchKernelGGL((k_dense_wave<WAVE_PRIO, 1>), dim3((unsigned)njobs), dim3(64), 0, s, d_grey, c.width, c.height, nbands, nwin, nseg, seg_tiles,
                      nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, rcc_dense_allow_skip(h), h->d_thr,
-                     d_cand, d_cand_count, fchunk);
+                     d_cand, d_cand_count, fchunk, 0);
   return hipGetLastError();
 }

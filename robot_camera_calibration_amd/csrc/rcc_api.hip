@@ -284,6 +284,16 @@ int rcc_set_dense_variant(rcc_handle* h, int variant)
   h->dense_variant = variant;
   return p;
 }
+// k_dense_wave as gangs of eight windows: sync_rows = 0 off, else a power of two (tile rows between the gang's barriers);
+// segments = 0: as the single-window form
+int rcc_set_dense_gang(rcc_handle* h, int sync_rows, int segments)
+{
+  if (!h || sync_rows < 0 || (sync_rows & (sync_rows - 1)) || segments < 0) return RCC_ERR_ARG;
+  int p = h->dense_gang_sync;
+  h->dense_gang_sync = sync_rows;
+  h->dense_gang_seg = segments;
+  return p;
+}
 int rcc_set_dense_skip(rcc_handle* h, int on)
 {
   if (!h) return RCC_ERR_ARG;

@@ -112,6 +112,8 @@ struct rcc_handle {
   int host_chunk_frames;    // 0: automatic (about 192 MiB per chunk); > 0: frames per chunk; < 0: one copy of the whole batch, then the kernels
   int pipeline_chunks;      // 0/1: one pass over the whole batch on one stream; n > 1: n chunks alternating over two streams
   int dense_variant, ingest_variant;
+  int dense_gang_sync;      // k_dense_wave: 0 = every window its own workgroup; n (a power of two) = gangs of eight windows meeting every n tile rows
+  int dense_gang_seg;       // segments per frame of the gang form (0: as the single-window form)
   int dense_skip;           // 1: the fast dense kernel may skip flat wave-rows (exact); 0: never (A/B, tests)
   int pnp_variant;          // -1 auto, 0 lane per target, 1 wavefront per target (board)
   int pnp_solver;           // 0 eigen, 1 Cholesky (default)

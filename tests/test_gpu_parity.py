@@ -480,6 +480,29 @@ def test_compact_threshold_map_identical(torch_cuda, w, h, n):
     det.close()
 
 
+def test_dense_gang_form_identical(torch_cuda):
+    """rcc_set_dense_gang: the step's threshold + corner kernel as gangs of eight windows that meet every n tile rows (built
+    to bound the re-reads at the window seams; measured 20 % slower, so not the default): same records, same threshold map"""
+    torch = torch_cuda
+    n = 6
+    for (w, h) in ((1920, 1080), (640, 480), (3840, 2160)):
+        cfg = _make(w=w, h=h, B=n)
+        det = api.Detector(cfg)
+        frames, _ = _render(torch, det, cfg, n, seed=55)
+        torch.cuda.synchronize()
+        d0, f0 = det.detect(frames, n)
+        img0 = det.fetch_images(n)
+        for sync, seg in ((1, 0), (4, 3), (16, 2)):
+            det.set_dense_gang(sync, seg)
+            d1, f1 = det.detect(frames, n)
+            assert "8>" in det.last_dense_kernel()
+            img1 = det.fetch_images(n)
+            assert d1.tobytes() == d0.tobytes() and f1.tobytes() == f0.tobytes()
+            assert (img1["bin"] == img0["bin"]).all() and (img1["cand_count"] == img0["cand_count"]).all()
+        det.set_dense_gang(0, 0)
+        det.close()
+
+
 def test_fused_grid_pnp_identical(torch_cuda):
     """lattice indexing + pose in one kernel (default) vs two kernels: the same records and corner tables"""
     torch = torch_cuda
