@@ -1,9 +1,10 @@
 // grid_frame.h -- the per-frame bodies of stages a4.3 and a6 (see k_grid.hip) as device functions.
-//   ring_valid_wave: a4.3's ring test at a refined position, called by the sub-pixel kernel for the corner it has just refined
-//                   (16 lanes take the 16 ring samples): no launch of its own, and the loads hide among 80 000 other waves.
-//   index_frame:    a4.3's de-duplication + a6, one wavefront per frame: as its own kernel (k_grid_index) or in front of the
-//                   board pose solve in one kernel (k_grid_pnp in k_pnp.hip: both are one-wavefront-per-frame dependency
-//                   chains, and a frame's pose needs only that frame's lattice).
+//   validate_frame: a4.3, spread over the 256 threads of a block (k_validate, k_grid.hip): one candidate per thread.
+//   index_frame:    a6, one wavefront per frame: as its own kernel (k_grid_index) or in front of the board pose solve in
+//                   one kernel (k_grid_pnp in k_pnp.hip: both are one-wavefront-per-frame dependency chains, and a frame's
+//                   pose needs only that frame's lattice).
+// They are separate launches because the pose solver's register budget (one wavefront per SIMD) would otherwise be paid by
+// the validation's helper wavefronts too: a 256-thread block with that budget fills a whole CU.
 #pragma once
 #include "rcc_internal.h"
 #include "wave_reduce.h"
@@ -89,19 +90,6 @@ __device__ __forceinline__ bool ring_ok(const BinSrc& b, int w, int h, int x, in
   return !any127 && tr == 4;
 }
 
-// the same test made by a wavefront for ONE position (wave-uniform x, y): lane l takes ring sample l & 15 (the four quarter-
-// waves repeat each other), the transitions are counted on a ballot
-__device__ __forceinline__ bool ring_valid_wave(const BinSrc& b, int w, int h, int x, int y, int lane)
-{
-  if (x < 5 || y < 5 || x >= w - 5 || y >= h - 5) return false;
-  const int k = lane & 15;
-  const int xx = x + c_ring16[k][0], yy = y + c_ring16[k][1];
-  const int v = b.at(xx, yy);
-  const int nxt = __shfl(v, (lane & 48) | ((lane + 1) & 15), 64);
-  const unsigned long long diff = __ballot(v != nxt), flat = __ballot(v == 127);
-  return ((flat & 0xFFFFull) == 0ull) && (__popcll(diff & 0xFFFFull) == 4);
-}
-
 #define GRID_NOPOS 0x7FFF7FFFu                    // farther than any radius from every valid position (coordinates < 16384)
 #define LABP(i, j) sm.labp[((i) + GM) * GW + ((j) + GM)]
 
@@ -174,39 +162,47 @@ __device__ __forceinline__ int nearest_free(const int (&pxr)[4], const int (&pyr
   return (int)(b & 255ull);
 }
 
-// ---- a4.3 (second half) + a6 of frame f, ONE wavefront.  The ring test at the rounded refined position was made by the
-// sub-pixel kernel where the position was produced (k_subpix.hip: vpos[i] = packed rounded pixel, or GRID_NOPOS); here the
-// surviving entries are de-duplicated and compacted in list order into the frame's kept lists (LDS for the stages below,
-// global memory for the callers' taps), then the board is indexed.  Returns true when the lattice was found: its corners
-// are then also at sm.xy[2 * sm.order[k]], k = 0..cols*rows-1.
-struct grid_smem {
-  int32_t px[RCC_MAX_KEPT], py[RCC_MAX_KEPT];     // validated points (rounded refined pixel), in list order
-  double xy[2 * RCC_MAX_KEPT];
-  uint32_t pos[RCC_MAX_KEPT];                     // a4.3: packed rounded refined pixel x | y << 16 of list entry i; GRID_NOPOS where it failed the ring test
+// ---- a4.3: validation of the refined corners of frame f, NT threads (one candidate per thread and pass): ring test at the
+// rounded refined position, de-duplication, ordered compaction into the frame's kept lists (global) + fc[f].nkept
+struct valid_smem {
   int32_t score[RCC_MAX_KEPT];
+  uint32_t pos[RCC_MAX_KEPT];      // packed rounded refined pixel x | y << 16 of list entry i; GRID_NOPOS where it failed the ring test
   uint8_t keep[RCC_MAX_KEPT];
-  int32_t labp[GW * GW];                          // packed coordinates x | y << 16 of the point labelled (i, j); -1: empty
-  int16_t tmp[RCC_MAX_KEPT], t2[RCC_MAX_KEPT];
-  int32_t order[RCC_MAX_KEPT];
+  int32_t wcnt[4];
 };
-__device__ __forceinline__ bool index_frame(grid_smem& sm, const int f, const int lane, int w, int h,
-                                            const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                            const double* __restrict__ pre_xy, const uint32_t* __restrict__ vpos, int dedupe_radius,
-                                            rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out,
-                                            int target_kind, int cols, int rows, rcc_frame_corners* __restrict__ fc)
+template <int NT>
+__device__ __forceinline__ void validate_frame(valid_smem& sm, const int f, const int tid,
+                                               const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
+                                               const uint8_t* __restrict__ thr, int nbands, int w, int h,
+                                               const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
+                                               const double* __restrict__ pre_xy, int xj_check, int dedupe_radius,
+                                               rcc_frame_corners* __restrict__ fc,
+                                               rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out)
 {
+  static_assert(NT == 64 || NT == 256, "one or four wavefronts");
+  const int lane = tid & 63, wv = tid >> 6;
   rcc_frame_corners* out = fc + f;
-  if (out->status != 0) return false;   // overflow flagged by the list stage: the frame yields nothing
-  const int n = uni(npre[f]);
-  for (int i = lane; i < n; i += 64) {
-    sm.pos[i] = vpos[(size_t)f * RCC_MAX_KEPT + i];
+  if (out->status != 0) return;         // overflow flagged by the list stage: the frame yields nothing
+  BinSrc b;
+  b.bin = bin ? bin + (size_t)f * w * h : nullptr;
+  b.grey = grey + (size_t)f * w * h;
+  b.thr = thr ? thr + (size_t)f * nbands * (h >> 2) * RCC_THR_PITCH : nullptr;
+  b.w = w; b.th = h >> 2;
+  const int n = npre[f];
+
+  for (int i = tid; i < n; i += NT) {
+    const double x = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2], y = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2 + 1];
+    const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
     sm.score[i] = pre[(size_t)f * RCC_MAX_KEPT + i].score;
+    bool v = (xi >= 5 && yi >= 5 && xi < w - 5 && yi < h - 5);
+    if (v && xj_check) v = ring_ok(b, w, h, xi, yi);
+    sm.pos[i] = v ? ((unsigned)xi | ((unsigned)yi << 16)) : GRID_NOPOS;
   }
   __syncthreads();
   // de-duplication: entry i goes if a valid entry within +-dedupe_radius has a larger score (or the same score and a smaller
   // index).  An entry that failed the ring test sits at GRID_NOPOS, out of every valid entry's reach.  Branch-free and
   // unrolled (an early exit made every iteration wait for its own LDS round trip).
-  for (int i = lane; i < n; i += 64) {
+  for (int i = tid; i < n; i += NT) {
     const unsigned pi = sm.pos[i];
     const int xi = (int)(pi & 0xFFFFu), yi = (int)(pi >> 16), si = sm.score[i];
     bool keep = pi != GRID_NOPOS;
@@ -223,28 +219,56 @@ __device__ __forceinline__ bool index_frame(grid_smem& sm, const int f, const in
   __syncthreads();
   // ordered compaction
   int m = 0;
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
+  for (int base = 0; base < n; base += NT) {
+    const int i = base + tid;
     const bool k = (i < n) && sm.keep[i];
     const unsigned long long bal = __ballot(k);
-    if (k) {
-      const int o = m + __popcll(bal & ((1ull << lane) - 1ull));
-      const unsigned pi = sm.pos[i];
-      const int xi = (int)(pi & 0xFFFFu), yi = (int)(pi >> 16);
-      const double x = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2], y = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2 + 1];
-      sm.px[o] = xi; sm.py[o] = yi;
-      sm.xy[2 * o] = x; sm.xy[2 * o + 1] = y;
-      rcc_cand e;
-      e.x = (int16_t)xi; e.y = (int16_t)yi; e.score = sm.score[i];
-      kept_out[(size_t)f * RCC_MAX_KEPT + o] = e;
-      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2] = x;
-      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2 + 1] = y;
+    int before = 0, total = __popcll(bal);
+    if (NT > 64) {
+      if (lane == 0) sm.wcnt[wv] = total;
+      __syncthreads();
+      total = 0;
+#pragma unroll
+      for (int q = 0; q < NT / 64; ++q) { const int c = sm.wcnt[q]; before += (q < wv) ? c : 0; total += c; }
     }
-    m += __popcll(bal);
+    if (k) {
+      const int o = m + before + __popcll(bal & ((1ull << lane) - 1ull));
+      const unsigned pi = sm.pos[i];
+      rcc_cand e;
+      e.x = (int16_t)(pi & 0xFFFFu); e.y = (int16_t)(pi >> 16); e.score = sm.score[i];
+      kept_out[(size_t)f * RCC_MAX_KEPT + o] = e;
+      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2] = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2];
+      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2 + 1] = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2 + 1];
+    }
+    m += total;
+    if (NT > 64) __syncthreads();        // wcnt is rewritten by the next pass
+  }
+  if (tid == 0) out->nkept = m;
+}
+
+// ---- a6: board indexing of frame f from its kept lists (validate_frame's output), ONE wavefront.  Returns true when the
+// board lattice was found: its corners are then also at sm.xy[2 * sm.order[k]], k = 0..cols*rows-1.
+struct grid_smem {
+  int32_t px[RCC_MAX_KEPT], py[RCC_MAX_KEPT];     // validated points (rounded refined pixel), in list order
+  double xy[2 * RCC_MAX_KEPT];
+  int32_t labp[GW * GW];                          // packed coordinates x | y << 16 of the point labelled (i, j); -1: empty
+  int16_t tmp[RCC_MAX_KEPT], t2[RCC_MAX_KEPT];
+  int32_t order[RCC_MAX_KEPT];
+};
+__device__ __forceinline__ bool index_frame(grid_smem& sm, const int f, const int lane, int w, int h,
+                                            const rcc_cand* __restrict__ kept, const double* __restrict__ kept_xy,
+                                            int target_kind, int cols, int rows, rcc_frame_corners* __restrict__ fc)
+{
+  rcc_frame_corners* out = fc + f;
+  if (out->status != 0) return false;   // overflow flagged by the list stage: the frame yields nothing
+  const int nk = uni(out->nkept);
+  for (int k = lane; k < nk && k < RCC_MAX_KEPT; k += 64) {
+    const rcc_cand e = kept[(size_t)f * RCC_MAX_KEPT + k];
+    sm.px[k] = e.x; sm.py[k] = e.y;
+    sm.xy[2 * k] = kept_xy[((size_t)f * RCC_MAX_KEPT + k) * 2];
+    sm.xy[2 * k + 1] = kept_xy[((size_t)f * RCC_MAX_KEPT + k) * 2 + 1];
   }
   __syncthreads();
-  const int nk = m;
-  if (lane == 0) out->nkept = nk;
 
   // ---- a6 board indexing
   const int need = cols * rows;

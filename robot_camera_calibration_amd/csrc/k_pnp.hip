@@ -151,12 +151,10 @@ __global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* 
                    img_scratch + (size_t)f * 2 * RCC_MAX_BOARD_CORNERS, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, det, ndet);
 }
 
-// a4.3's de-duplication + a6 + a7 of one frame in one wavefront: the corners that passed the ring test (made in k_subpix) are
-// de-duplicated and indexed (grid_frame.h), then the pose comes from the lattice that leaves in LDS.  Both stages are single
-// dependency chains per frame; run as two kernels the second waits for the slowest frame of the first.
-__global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                                 const double* __restrict__ pre_xy, const uint32_t* __restrict__ vpos, int dedupe_radius,
-                                                 rcc_cand* __restrict__ kept, double* __restrict__ kept_xy,
+// a6 + a7 of one frame in one wavefront: lattice indexing of the validated corners (grid_frame.h), then the pose from the
+// lattice it leaves in LDS.  Both stages are single dependency chains per frame; run as two kernels the second waits for the
+// slowest frame of the first.  (a4.3, the validation, is a launch of its own: k_validate, one candidate per thread.)
+__global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* __restrict__ kept, const double* __restrict__ kept_xy,
                                                  int cols, int rows, rcc_frame_corners* __restrict__ fc,
                                                  const double* __restrict__ board_obj, double square, int board_id, int reference_mode,
                                                  rcc_cam cam, rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
@@ -167,7 +165,7 @@ __global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* _
   const int f = blockIdx.x;
   const int lane = threadIdx.x;
   GTRACE(0);
-  const bool found = index_frame(sm, f, lane, w, h, pre, npre, pre_xy, vpos, dedupe_radius, kept, kept_xy, RCC_TARGET_CHECKERBOARD, cols, rows, fc);
+  const bool found = index_frame(sm, f, lane, w, h, kept, kept_xy, RCC_TARGET_CHECKERBOARD, cols, rows, fc);
   __syncthreads();
   GTRACE(5);
   if (!found) { if (lane == 0) ndet[f] = 0; return; }       // wave-uniform
@@ -280,18 +278,20 @@ hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s)
   return hipGetLastError();
 }
 
-// de-duplication + lattice + board pose in one launch (wave per frame); same outputs as rcc_launch_grid followed by rcc_launch_pnp_board
+// validation, then lattice + board pose in one launch (wave per frame); same outputs as rcc_launch_grid followed by rcc_launch_pnp_board
 hipError_t rcc_launch_grid_pnp(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s)
 {
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
+  hipError_t e = rcc_launch_validate(h, d_grey, d_bin, nframes, s);
+  if (e != hipSuccess) return e;
   rcc_cam cam;
   cam.fx = c.K[0]; cam.cx = c.K[2]; cam.fy = c.K[4]; cam.cy = c.K[5];
   for (int i = 0; i < 8; ++i) cam.D[i] = c.D[i];
   cam.model = h->undist ? RCC_DIST_NONE : c.dist_model;
   cam.solver = h->pnp_solver;
-  hipLaunchKernelGGL(k_grid_pnp, dim3(nframes), dim3(64), 0, s, c.width, c.height, h->d_pre, h->d_npre, h->d_pre_xy, h->d_vpos, 2,
-                     h->d_kept, h->d_kept_xy, c.board_cols, c.board_rows, h->d_fc, h->d_board_obj, c.board_square, c.board_id,
+  hipLaunchKernelGGL(k_grid_pnp, dim3(nframes), dim3(64), 0, s, c.width, c.height, h->d_kept, h->d_kept_xy,
+                     c.board_cols, c.board_rows, h->d_fc, h->d_board_obj, c.board_square, c.board_id,
                      c.reference_mode, cam, h->d_det, h->d_ndet);
   return hipGetLastError();
 }

@@ -11,7 +11,6 @@
 // Compiled with -ffp-contract=off: every operation below is one rounded IEEE operation.
 #include "rcc_internal.h"
 #include "wave_reduce.h"
-#include "grid_frame.h"      // BinSrc, ring_valid_wave: a4.3's ring test at the refined position
 
 #define SP_MAXW 7
 #define SP_MAXP (2 * SP_MAXW + 3)
@@ -22,9 +21,7 @@
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
                                                rcc_subpix_params sp, const rcc_subpix_lane* __restrict__ tab, int kstride,
-                                               double* __restrict__ pre_xy,
-                                               const uint8_t* __restrict__ bin, const uint8_t* __restrict__ thr, int nbands, int xj_check,
-                                               uint32_t* __restrict__ vpos)
+                                               double* __restrict__ pre_xy)
 {
   __shared__ double S[SP_MAXP * SP_MAXP];
   const int f = blockIdx.y, q = blockIdx.x;
@@ -135,32 +132,14 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
     pre_xy[((size_t)f * kstride + q) * 2] = cx;
     pre_xy[((size_t)f * kstride + q) * 2 + 1] = cy;
   }
-  // a4.3, first half (board targets: vpos != null): is the refined position, rounded to a pixel, an X-junction of the
-  // threshold map?  Here the position is in registers and the 16 ring samples are one load per lane among ~80 000 other
-  // waves; as a stage of its own it was a launch (30 us) in front of the one-wavefront-per-frame lattice kernel.
-  if (vpos) {
-    const int xi = (int)floor(cx + 0.5), yi = (int)floor(cy + 0.5);
-    bool v = (xi >= 5 && yi >= 5 && xi < w - 5 && yi < h - 5);
-    if (xj_check) {
-      BinSrc b;
-      b.bin = bin ? bin + (size_t)f * w * h : nullptr;
-      b.grey = g;
-      b.thr = thr ? thr + (size_t)f * nbands * (h >> 2) * RCC_THR_PITCH : nullptr;
-      b.w = w; b.th = h >> 2;
-      v = ring_valid_wave(b, w, h, xi, yi, lane);
-    }
-    if (lane == 0) vpos[(size_t)f * kstride + q] = v ? ((unsigned)xi | ((unsigned)yi << 16)) : GRID_NOPOS;
-  }
 }
 
-hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s)
+hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s)
 {
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
   int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
   hipLaunchKernelGGL(k_subpix, dim3(max_kept, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
-                     h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy,
-                     h->bin_from_thr ? nullptr : d_bin, h->bin_from_thr ? h->d_thr : nullptr, (c.width + RCC_BAND_W - 1) / RCC_BAND_W, c.xj_check,
-                     c.target_kind == RCC_TARGET_CHECKERBOARD ? h->d_vpos : nullptr);
+                     h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy);
   return hipGetLastError();
 }

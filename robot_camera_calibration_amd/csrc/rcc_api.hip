@@ -117,7 +117,7 @@ void rcc_destroy(rcc_handle* h)
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = { h->d_map, h->d_tilebox, h->d_flat, h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
-                   h->d_kept, h->d_kept_xy, h->d_vpos, h->d_ref_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
+                   h->d_kept, h->d_kept_xy, h->d_ref_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
                    h->d_board_obj, h->d_img_scratch, h->d_family, h->d_sp_tab };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_det) (void)hipHostFree(h->h_det);
@@ -196,7 +196,6 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   ALLOC(h->d_pre_xy, B * (size_t)h->kept_cap * 2 * sizeof(double));
   ALLOC(h->d_kept, B * RCC_MAX_KEPT * sizeof(rcc_cand));
   ALLOC(h->d_kept_xy, B * RCC_MAX_KEPT * 2 * sizeof(double));
-  ALLOC(h->d_vpos, B * RCC_MAX_KEPT * sizeof(uint32_t));
   ALLOC(h->d_fc, B * sizeof(rcc_frame_corners));
   ALLOC(h->d_det, B * (size_t)cfg->max_targets * sizeof(rcc_detection));
   ALLOC(h->d_ndet, B * sizeof(int32_t));
@@ -410,7 +409,7 @@ static int launch_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d
   const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
   if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
   HIPCHK(h, rcc_launch_list(h, d_cand, d_cand_count, nframes, s));
-  HIPCHK(h, rcc_launch_subpix(h, d_grey, d_bin, nframes, s));
+  HIPCHK(h, rcc_launch_subpix(h, d_grey, nframes, s));
   const bool fused = !fid && h->fuse_grid_pnp && rcc_grid_pnp_applicable(h);   // lattice indexing + pose in one launch
   if (fid) HIPCHK(h, rcc_launch_fid(h, d_grey, nframes, s));
   else if (!fused) HIPCHK(h, rcc_launch_grid(h, d_grey, d_bin, nframes, s));
@@ -470,7 +469,7 @@ static rcc_handle handle_view(const rcc_handle* h, int f0)
   v.d_cand += o * (size_t)h->cfg.max_candidates; v.d_cand_count += o;
   v.d_pre += o * (size_t)h->kept_cap; v.d_npre += o; v.d_pre_xy += o * (size_t)h->kept_cap * 2;
   if (v.d_ref_xy) v.d_ref_xy += o * (size_t)h->kept_cap * 2;
-  v.d_kept += o * RCC_MAX_KEPT; v.d_kept_xy += o * RCC_MAX_KEPT * 2; v.d_vpos += o * RCC_MAX_KEPT;
+  v.d_kept += o * RCC_MAX_KEPT; v.d_kept_xy += o * RCC_MAX_KEPT * 2;
   v.d_fc += o; v.d_det += o * (size_t)h->cfg.max_targets; v.d_ndet += o;
   v.d_img_scratch += o * 2 * RCC_MAX_BOARD_CORNERS;
   return v;

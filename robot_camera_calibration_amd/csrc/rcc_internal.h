@@ -83,7 +83,6 @@ struct rcc_handle {
   double* d_ref_xy;       // fiducial handles: B x kept_cap x 2, refined corner of list entry i where it is a corner of a decoded quad (refine_edges form)
   rcc_cand* d_kept;       // B x 256 (validated, rounded refined pixel)
   double* d_kept_xy;      // B x 256 x 2
-  uint32_t* d_vpos;       // B x 256: a4.3 ring test of list entry i at its rounded refined position: x | y << 16, or 0x7FFF7FFF (board targets)
   rcc_frame_corners* d_fc;  // B
   rcc_detection* d_det;     // B x max_targets
   int32_t* d_ndet;          // B
@@ -139,7 +138,8 @@ hipError_t rcc_launch_dense_runs(rcc_handle* h, const uint8_t* d_grey, int nfram
 hipError_t rcc_launch_pack_records(rcc_handle* h, int nframes, int frame_offset, double* d_table, hipStream_t s);
 hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t* d_cand_count,
                            int nframes, hipStream_t s);
-hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s);
+hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);
+hipError_t rcc_launch_validate(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s);
 hipError_t rcc_launch_grid(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s);
 hipError_t rcc_launch_expand_bin(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin, hipStream_t s);
 hipError_t rcc_launch_fid(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s);
