@@ -192,10 +192,12 @@ int orc_fid_decode(const uint8_t* g, int w, int h, const double q[8], const uint
  *   qi        the quad's integer corners (x, y), clockwise on screen; black lies on the (-dy, dx) side of every edge a -> b
  *   samples   16 per edge at a + alpha (b - a), alpha = (s + 2) / 19, s = 0..15 (the two positions nearest either corner are
  *             left out: there the other edge bends the profile)
- *   scan      offsets k / 4 px along the OUTWARD normal n = (dy, -dx) / |d|, k = -12 .. 12; g1 = the image one pixel further
+ *   scan      offsets k / 2 px along the OUTWARD normal n = (dy, -dx) / |d|, k = -6 .. 6 (half-pixel steps measure the same
+ *             corner error against the renderer's ground truth as appendix C.4's quarter-pixel steps, at half the samples);
+ *             g1 = the image one pixel further
  *             out, g2 = one pixel further in, both sampled bilinearly in 1/16-px fixed point as 256 x grey (bil16; a step
  *             whose samples leave the image is skipped); weight (g1 - g2)^2 where g1 > g2 (white outside), else 0;
- *             offset = (sum k w / sum w) / 4  -- integer sums
+ *             offset = (sum k w / sum w) / 2  -- integer sums
  *   line      moments of the refined points relative to a, summed over the 16 samples along the pairing tree
  *             v[l] += v[l ^ 8], ^ 4, ^ 2, ^ 1 (what a 16-lane butterfly does); centroid E, covariance C; the normal is the
  *             eigenvector of C's smaller eigenvalue, taken in its well-conditioned form; fewer than 4 valid samples or a
@@ -236,8 +238,8 @@ static void refine_edges_pass(const uint8_t* g, int w, int h, const double qi[8]
       const double tx = alpha * dx, ty = alpha * dy;
       const double x0 = ax + tx, y0 = ay + ty;
       long long Mn = 0, Mc = 0;
-      for (int k = -12; k <= 12; ++k) {
-        const double t1 = (double)(k + 4) * 0.25, t2 = (double)(k - 4) * 0.25;
+      for (int k = -6; k <= 6; ++k) {
+        const double t1 = (double)(k + 2) * 0.5, t2 = (double)(k - 2) * 0.5;
         const double u1 = t1 * nx, v1 = t1 * ny, u2 = t2 * nx, v2 = t2 * ny;
         const double x1 = x0 + u1, y1 = y0 + v1, x2 = x0 + u2, y2 = y0 + v2;
 if (!(x1 >= 0.0 && y1 >= 0.0 && x1 <= (double)(w - 2) && y1 <= (double)(h - 2) &&
@@ -248,7 +250,7 @@ if (!(x1 >= 0.0 && y1 >= 0.0 && x1 <= (double)(w - 2) && y1 <= (double)(h - 2) &
         Mn += wt * k; Mc += wt;
       }
       if (Mc == 0 || !(L > 0.0)) { sx[s] = sy[s] = sxx[s] = sxy[s] = syy[s] = sn[s] = 0.0; continue; }
-      const double n0 = ((double)Mn / (double)Mc) * 0.25;
+      const double n0 = ((double)Mn / (double)Mc) * 0.5;
       const double ox = n0 * nx, oy = n0 * ny;
       const double rx = tx + ox, ry = ty + oy;          /* refined point relative to a */
       sx[s] = rx; sy[s] = ry; sxx[s] = rx * rx; sxy[s] = rx * ry; syy[s] = ry * ry; sn[s] = 1.0;

@@ -238,10 +238,12 @@ __device__ bool fid_decode_group(const uint8_t* __restrict__ g, int w, int h, co
 //   qi        the quad's corners rounded to pixels, clockwise on screen; black lies on the (-dy, dx) side of every edge a -> b
 //   samples   16 per edge at a + alpha (b - a), alpha = (s + 2) / 19, s = 0..15 (the two positions nearest either corner are
 //             left out: there the other edge bends the profile)
-//   scan      33 bilinear samples (1/16-px fixed point, 256 x grey) along the OUTWARD normal n = (dy, -dx) / |d| at offsets
-//             j / 4 px, j = -16 .. 16; step k = -12 .. 12 pairs j = k + 4 (one pixel further out) with j = k - 4 (further in):
+//   scan      17 bilinear samples (1/16-px fixed point, 256 x grey) along the OUTWARD normal n = (dy, -dx) / |d| at offsets
+//             j / 2 px, j = -8 .. 8; step k = -6 .. 6 pairs j = k + 2 (one pixel further out) with j = k - 2 (further in):
 //             weight (g1 - g2)^2 where g1 > g2 (white outside) and both samples lie inside the image, else 0;
-//             offset = (sum k w / sum w) / 4 -- integer sums
+//             offset = (sum k w / sum w) / 2 -- integer sums.  (Half-pixel steps: the same corner error against the
+//             renderer's ground truth as C.4's quarter-pixel steps -- rms 0.039 px -- at half the loads, and the loads are
+//             what this stage costs: scattered byte reads, 16 lanes per quad)
 //   line      moments of the refined points relative to a, summed over the 16 samples along the pairing tree of a 16-lane
 //             xor butterfly (offsets 8, 4, 2, 1; IEEE addition commutes, so every lane ends with the same totals);
 //             centroid E, covariance C; the normal is the eigenvector of C's smaller eigenvalue in its well-conditioned
@@ -253,6 +255,9 @@ __device__ bool fid_decode_group(const uint8_t* __restrict__ g, int w, int h, co
 // the corners are the same bits.
 __device__ __forceinline__ double fid_tree16(double v)
 {
+#ifdef RCC_FID_ABL_NOTREE
+  return v * 16.0;                               // timing-only ablation: no cross-lane sums
+#endif
 #pragma unroll
   for (int off = 8; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 16);
   return v;
@@ -282,19 +287,41 @@ __device__ void fid_refine_edges_group(const uint8_t* __restrict__ g, int w, int
     const double alpha = (double)(s + 2) / 19.0;
     const double tx = alpha * dx, ty = alpha * dy;
     const double x0 = ax + tx, y0 = ay + ty;
-    int P[33];                                   // 256 x grey at offset j / 4 along the normal, -1 outside the image
+    // 256 x grey at offset j / 2 along the normal (-1 outside the image), in three passes so that the 34 reads of an edge
+    // are in flight together: positions and weights first, then every load, then the blends.  (Sample by sample, each
+    // blend waited for its own two loads: 17 memory latencies per edge, 0.4 ms of this kernel per 1024 frames.)
+    int P[17], off[17], fxy[17];
 #pragma unroll
-    for (int j = -16; j <= 16; ++j) {
-      const double t = (double)j * 0.25;
+    for (int j = -8; j <= 8; ++j) {
+      const double t = (double)j * 0.5;
       const double u = t * nx, v = t * ny;
       const double x = x0 + u, y = y0 + v;
       const bool in = valid && x >= 0.0 && y >= 0.0 && x <= (double)(w - 2) && y <= (double)(h - 2);
-      P[j + 16] = in ? fid_bil16(g, w, x, y) : -1;
+      const int X = (int)rint((in ? x : 0.0) * 16.0), Y = (int)rint((in ? y : 0.0) * 16.0);
+      off[j + 8] = in ? (Y >> 4) * w + (X >> 4) : -1;
+      fxy[j + 8] = (X & 15) | ((Y & 15) << 4);
+    }
+    unsigned short r0[17], r1[17];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) {
+#ifdef RCC_FID_ABL_NOLOAD
+      r0[j] = (unsigned short)off[j]; r1[j] = (unsigned short)(off[j] >> 3);       // timing-only ablation: no image reads
+#else
+      const uint8_t* p = g + (size_t)(off[j] < 0 ? 0 : off[j]);
+      __builtin_memcpy(&r0[j], p, 2);
+      __builtin_memcpy(&r1[j], p + w, 2);
+#endif
+    }
+#pragma unroll
+    for (int j = 0; j < 17; ++j) {
+      const int fx = fxy[j] & 15, fy = fxy[j] >> 4;
+      const int b = (16 - fx) * (16 - fy) * (int)(r0[j] & 255) + fx * (16 - fy) * (int)(r0[j] >> 8) + (16 - fx) * fy * (int)(r1[j] & 255) + fx * fy * (int)(r1[j] >> 8);
+      P[j] = off[j] < 0 ? -1 : b;
     }
     long long Mn = 0, Mc = 0;
 #pragma unroll
-    for (int k = -12; k <= 12; ++k) {
-      const int g1 = P[k + 4 + 16], g2 = P[k - 4 + 16];
+    for (int k = -6; k <= 6; ++k) {
+      const int g1 = P[k + 2 + 8], g2 = P[k - 2 + 8];
       if (g1 >= 0 && g2 >= 0 && g1 > g2) {
         const long long wt = (long long)(g1 - g2) * (long long)(g1 - g2);
         Mn += wt * k; Mc += wt;
@@ -302,7 +329,7 @@ __device__ void fid_refine_edges_group(const uint8_t* __restrict__ g, int w, int
     }
     double rx = 0.0, ry = 0.0, one = 0.0;
     if (Mc != 0 && L > 0.0) {
-      const double n0 = ((double)Mn / (double)Mc) * 0.25;
+      const double n0 = ((double)Mn / (double)Mc) * 0.5;
       const double ox = n0 * nx, oy = n0 * ny;
       rx = tx + ox; ry = ty + oy; one = 1.0;
     }
@@ -565,7 +592,9 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
         for (int c = 0; c < 8; ++c) qi[c] = (int)floor(q[c] + 0.5);
         const long long cri = (long long)(qi[2] - qi[0]) * (qi[5] - qi[3]) - (long long)(qi[3] - qi[1]) * (qi[4] - qi[2]);
         go = have && (cri > 0);
+#ifndef RCC_FID_ABL_NOREFINE
         fid_refine_edges_group(g, w, h, qi, lg, go, q);
+#endif
         if (go && lg == 0) {
           double* r = ref_xy + (size_t)f * kstride * 2;
 #pragma unroll

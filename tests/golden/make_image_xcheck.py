@@ -288,21 +288,21 @@ def refine_edges_np(grey, qi):
     n = np.stack([d[:, 1] / L, -d[:, 0] / L], 1)    # outward normal
     alpha = (np.arange(16) + 2) / 19.0
     base = a[:, None, :] + alpha[None, :, None] * d[:, None, :]                     # (4, 16, 2)
-    j = np.arange(-16, 17) * 0.25
-    pos = base[:, :, None, :] + j[None, None, :, None] * n[:, None, None, :]        # (4, 16, 33, 2)
+    j = np.arange(-8, 9) * 0.5
+    pos = base[:, :, None, :] + j[None, None, :, None] * n[:, None, None, :]        # (4, 16, 17, 2)
     inside = (pos[..., 0] >= 0) & (pos[..., 1] >= 0) & (pos[..., 0] <= w - 2) & (pos[..., 1] <= h - 2)
     X = np.rint(np.where(inside, pos[..., 0], 0.0) * 16.0).astype(np.int64)
     Y = np.rint(np.where(inside, pos[..., 1], 0.0) * 16.0).astype(np.int64)
     ix, iy, fx, fy = X >> 4, Y >> 4, X & 15, Y & 15
     Pv = (16 - fx) * (16 - fy) * g[iy, ix] + fx * (16 - fy) * g[iy, ix + 1] + (16 - fx) * fy * g[iy + 1, ix] + fx * fy * g[iy + 1, ix + 1]
-    k = np.arange(-12, 13)
-    g1, g2 = Pv[:, :, k + 4 + 16], Pv[:, :, k - 4 + 16]
-    ok = inside[:, :, k + 4 + 16] & inside[:, :, k - 4 + 16] & (g1 > g2)
+    k = np.arange(-6, 7)
+    g1, g2 = Pv[:, :, k + 2 + 8], Pv[:, :, k - 2 + 8]
+    ok = inside[:, :, k + 2 + 8] & inside[:, :, k - 2 + 8] & (g1 > g2)
     wt = np.where(ok, (g1 - g2) ** 2, 0)
     Mc = wt.sum(-1)
     Mn = (wt * k).sum(-1)
     valid = Mc > 0
-    n0 = np.where(valid, Mn / np.where(valid, Mc, 1), 0.0) * 0.25
+    n0 = np.where(valid, Mn / np.where(valid, Mc, 1), 0.0) * 0.5
     pts = (alpha[None, :, None] * d[:, None, :]) + n0[..., None] * n[:, None, :]    # relative to a
     lines = []
     for e in range(4):
