@@ -48,6 +48,7 @@ def parse(argv=None):
     ap.add_argument("--sync-steps", action="store_true", help="time K synchronous detect() calls instead of the submit/collect stream of K batches")
     ap.add_argument("--pipeline", type=int, default=1, help="chunks of the detector's two-stream pipeline per step (1: single pass)")
     ap.add_argument("--fiducials", default="", help="BASELINE.json configs[4]-style run: GXxGY planar grid of square fiducials per frame, e.g. 6x4")
+    ap.add_argument("--gather-side-stream", action="store_true", help="A/B: the per-step all_gather on a side stream instead of in line behind the batch")
     ap.add_argument("--no-pin", action="store_true", help="do not bind the rank's host threads to its GPU's NUMA node")
     ap.add_argument("--tag-refine", default="edges", choices=["edges", "subpix"], help="fiducial corner refinement: refine_edges form (default) or the cornerSubPix form")
     ap.add_argument("--fisheye", action="store_true", help="BASELINE.json configs[3]-style run: fisheye model (use with --width 3840 --height 2160 --batch 256)")
@@ -121,6 +122,21 @@ def rank_report(dist, dev, world, dt_local, steps, found_local, gather, pinned):
             "collective_backend": (dist.get_backend() if dist is not None else "none")}
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator is created; the contract of this script is ONE
+    JSON line there.  While the process group comes up, file descriptor 1 points at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def launch_ranks(a):
     """--gpus N > 1 without a launcher: start N ranks as a child torchrun.  This parent never imports torch and never
     makes a HIP call -- the devices are counted from sysfs (a rank that finds no device of its own fails by itself)."""
@@ -170,15 +186,25 @@ def run_steps(det, frames, B, gather, steps, sync_steps):
         # Every step's work -- all kernels, the device-to-host copy, the unpack, the all_gather -- is inside the region.
         slot_of_next = getattr(det, "_nsub", 0) & 1          # result slot (and record table) of the next submission
         before = getattr(gather, "before_submit", lambda s: None)
-        before(slot_of_next); det.submit(frames, B, **kw); slot_of_next ^= 1
+        # GPU ranks whose tables the detector packs: the collective is queued right behind the batch on the same stream
+        inline = bool(getattr(gather, "inline", False) and getattr(gather, "attached", False) and gather.dist is not None)
+
+        def sub(slot):
+            before(slot); det.submit(frames, B, **kw)
+            if inline:
+                gather.exchange(None, slot, False)
+        sub(slot_of_next); slot_of_next ^= 1
         for k in range(steps):
             if k + 1 < steps:
-                before(slot_of_next); det.submit(frames, B, **kw); slot_of_next ^= 1
+                sub(slot_of_next); slot_of_next ^= 1
             dets, _ = det.collect()
             run_steps.local_found = len(dets)
             if hasattr(det, "last_timings"):
                 run_steps.dense_ms.append(det.last_timings()["dense"])
-            found = gather.exchange(dets, getattr(det, "last_slot", 0), k == steps - 1)
+            if inline:
+                found = gather.count() if k == steps - 1 else -1
+            else:
+                found = gather.exchange(dets, getattr(det, "last_slot", 0), k == steps - 1)
     return found
 
 
@@ -376,12 +402,12 @@ def cpu_and_accuracy_legs(a, out, det, cfg, frames, poses, B, fid, tpf):
             for q, d in enumerate(rby.get(f, [])):              # against the sub-pixel pose of the same target
                 sub = [x for x in by.get(f, []) if x.id == d.id]
                 if sub:
-                    dr = max(dr, float(np.abs(np.array(list(d.rvec)) - np.array(list(sub[0].rvec))).max()))
+                    dr = max(dr, float(np.abs(synth.rodrigues(list(d.rvec)) - synth.rodrigues(list(sub[0].rvec))).max()))
                     dt_ = max(dt_, float(np.abs(np.array(list(d.tvec)) - np.array(list(sub[0].tvec))).max()))
         chkr.close()
         out["accuracy_reference_mode"] = {"frames": SA, "what": "cfg.reference_mode = 1: corners truncated to int before the pose solve, as corner_detections.cpp:53-54 does",
                                           "max_rvec_err_vs_oracle": racc["rvec"], "max_tvec_err_vs_oracle": racc["tvec"], "mismatches": racc["mism"],
-                                          "max_rvec_shift_vs_subpixel_pose": dr, "max_tvec_shift_vs_subpixel_pose_m": dt_}
+                                          "max_rotation_matrix_shift_vs_subpixel_pose": dr, "max_tvec_shift_vs_subpixel_pose_m": dt_}
     except Exception as e:
         out["accuracy_reference_mode"] = {"error": repr(e)}
     chk.close()
@@ -415,7 +441,10 @@ def main():
     dist = None
     if "WORLD_SIZE" in os.environ:          # launched by torchrun: the distributed path, whatever the world size (a world of
         import torch.distributed as dist    # one still runs the RCCL calls: init, barrier, all_gather of the record tables)
-        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        with _stdout_to_stderr():
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+            dist.barrier()                                           # the communicator (and RCCL's banner) comes up here
+            torch.cuda.synchronize()
         if dist.get_world_size() != a.gpus:
             sys.stderr.write("bench.py: RCCL world of %d ranks, --gpus %d\n" % (dist.get_world_size(), a.gpus))
             return 2
@@ -461,7 +490,7 @@ def main():
     torch.cuda.synchronize()
 
     tpf = fid[0] * fid[1] if fid else 1
-    gather = rdist.PoseGather(B, dev, world, dist, rank, targets_per_frame=tpf)
+    gather = rdist.PoseGather(B, dev, world, dist, rank, targets_per_frame=tpf, inline=not a.gather_side_stream)
     if dist is not None:
         gather.attach(det, frame_offset=first)      # the detector packs the records on the device, every batch
 
