@@ -87,9 +87,11 @@ int rcc_debug_pnp_probe(rcc_handle* h, const double* obj, const double* img, int
  * back on one stream (mode 0) or launched together on two streams (mode 1); mean milliseconds per pair. */
 int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,
                       void* d_cand, void* d_cand_count, int32_t mode, int32_t reps, float* mean_ms);
-/* experiment (scratch/t_grid_trace.py): per-frame phase time stamps of k_grid_pnp -- d_buf: nframes x 16 int64 (device), slots
+/* experiment (scratch/t_grid_trace.py): per-frame phase time stamps of k_grid_pnp -- d_buf: nframes x 24 int64 (device), slots
  * 0 start, 1 seeds done, 3 growth starts, 2 growth done, 5 lattice done, 6 pose done (10-ns ticks), 7 = seed attempt * 1000 + labels,
- * 8 homography starts, 9 DLT done, 10 refinement done, 11 homography returned, 12 initial pose done, 13 = refinement iterations;
+ * 8 homography starts, 9 DLT done, 10 refinement done, 11 homography returned, 12 initial pose done, 13 = refinement iterations,
+ * 16..23 = time spent in: H accumulate (full), H accumulate (trial), H 8x8 solve, H rest, pose accumulate (full), pose accumulate (trial),
+ * pose 6x6 solve, (unused);
  * NULL switches it off. */
 int rcc_debug_grid_trace(rcc_handle* h, void* d_buf);
 #endif

@@ -19,12 +19,15 @@
 // (the one recorded failure was the test's own: the Rodrigues round trip is not unique beyond |r| = pi) and is faster
 // (24 456 tag poses 0.45 -> 0.31 ms, board pose 0.27 -> 0.25 ms; profiles/r02_e_pnp_inline.txt).
 #ifdef RCC_EXPERIMENTS
-// experiment builds only: per-frame time stamps of k_grid_pnp's phases (rcc_debug_grid_trace): 16 slots per frame
+// experiment builds only: per-frame time stamps of k_grid_pnp's phases (rcc_debug_grid_trace): 24 slots per frame
 __device__ long long* g_grid_trace = nullptr;
-#define GTRACE(slot) do { if (g_grid_trace && lane == 0) g_grid_trace[(size_t)f * 16 + (slot)] = (long long)wall_clock64(); } while (0)
-#define GTRACE_VAL(slot, v) do { if (g_grid_trace && lane == 0) g_grid_trace[(size_t)f * 16 + (slot)] = (long long)(v); } while (0)
+#define GTRACE(slot) do { if (g_grid_trace && lane == 0) g_grid_trace[(size_t)f * 24 + (slot)] = (long long)wall_clock64(); } while (0)
+#define GTRACE_VAL(slot, v) do { if (g_grid_trace && lane == 0) g_grid_trace[(size_t)f * 24 + (slot)] = (long long)(v); } while (0)
 // solver phases (pnp_core.h): k < 100 a time stamp in slot k; k >= 100: the refinement's iteration count into slot 13
-#define RCC_PNP_PHASE(k) do { if (g_grid_trace && threadIdx.x == 0) { if ((k) >= 100) g_grid_trace[(size_t)blockIdx.x * 16 + 13] = (k) - 100; else g_grid_trace[(size_t)blockIdx.x * 16 + (k)] = (long long)wall_clock64(); } } while (0)
+#define RCC_PNP_PHASE(k) do { if (g_grid_trace && threadIdx.x == 0) { if ((k) >= 100) g_grid_trace[(size_t)blockIdx.x * 24 + 13] = (k) - 100; else g_grid_trace[(size_t)blockIdx.x * 24 + (k)] = (long long)wall_clock64(); } } while (0)
+// inner steps: category accumulators (10-ns ticks) in the free tail of the wavefront's LDS workspace (n <= 48 points)
+#define RCC_PNP_TIC() long long tic_ = (long long)wall_clock64()
+#define RCC_PNP_TOC(cat) do { const long long now_ = (long long)wall_clock64(); if (g_grid_trace && par.first() == 0) ((long long*)(par.ws() + 308))[cat] += now_ - tic_; tic_ = (long long)wall_clock64(); } while (0)
 #endif
 #include "pnp_core.h"
 #ifdef RCC_EXPERIMENTS
@@ -164,6 +167,9 @@ __global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* _
   __shared__ double s_img[2 * RCC_MAX_BOARD_CORNERS];
   const int f = blockIdx.x;
   const int lane = threadIdx.x;
+#ifdef RCC_EXPERIMENTS
+  if (threadIdx.x < 8) ((long long*)(ws + 308))[threadIdx.x] = 0;
+#endif
   GTRACE(0);
   const bool found = index_frame(sm, f, lane, w, h, kept, kept_xy, RCC_TARGET_CHECKERBOARD, cols, rows, fc);
   __syncthreads();
@@ -172,6 +178,10 @@ __global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* _
   board_pose_frame(f, lane, [&](int k, double& x, double& y) { const int o = sm.order[k]; x = sm.xy[2 * o]; y = sm.xy[2 * o + 1]; },
                    s_img, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, det, ndet);
   GTRACE(6);
+#ifdef RCC_EXPERIMENTS
+  // slots 16..23 <- the category accumulators of the solver's inner steps
+  if (g_grid_trace && threadIdx.x < 8) g_grid_trace[(size_t)f * 24 + 16 + threadIdx.x] = ((long long*)(ws + 308))[threadIdx.x];
+#endif
 }
 
 __global__ __launch_bounds__(64) void k_pnp_generic_wave(const double* __restrict__ obj, const double* __restrict__ img,

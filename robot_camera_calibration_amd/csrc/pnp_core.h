@@ -43,6 +43,10 @@
 #ifndef RCC_PNP_PHASE
 #define RCC_PNP_PHASE(k)      /* experiment builds: a time stamp per solver phase (k_pnp.hip) */
 #endif
+#ifndef RCC_PNP_TIC
+#define RCC_PNP_TIC()         /* experiment builds: per-category time accumulators of the solver's inner steps */
+#define RCC_PNP_TOC(cat)
+#endif
 
 namespace rccpnp {
 
@@ -179,42 +183,55 @@ RCC_NI RCC_HD inline void sym_solve(int n, const double* A, const double* b, dou
 // algorithm solves them by SVD (A.8) / eigen-decomposition (A.4); for a well-conditioned SPD matrix
 // the solutions agree to ~1e-12 relative.  A pivot below 1e-13 of the largest diagonal entry means
 // the SVD path would have dropped a direction: then fall back to sym_solve, which does.
+// The matrix is read ONCE (its lower triangle, one batch of loads) and the factor lives in registers (static indices, fully
+// unrolled): with the wave-per-target mapping A sits in the LDS workspace, and a factor kept there made every one of
+// its ~N^3/3 uses an LDS round trip on the solver's single dependency chain -- the 8x8 solve of the homography
+// refinement took 6 us, the largest single piece of the board pose.  Damping: the diagonal is taken as A_ii + dadd[i]
+// (dadd != null: the LMSolver form) or A_ii * dmul (CvLevMarq's), so the caller no longer builds a damped copy in memory.
+// Same operations in the same order as the in-memory form: identical bits.
 template <int N>
-RCC_HD inline void spd_solve(int solver, const double* A, const double* b, double* x, double* L /* N*N workspace */)
+RCC_HD inline void spd_solve_damped(int solver, const double* A, const double* dadd, double dmul, const double* b, double* x)
 {
+  constexpr int T = N * (N + 1) / 2;
+  double M[T], Lr[T];                      // lower triangles, row-major: (i, j <= i) at i (i + 1) / 2 + j
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] = A[i * N + j];
+#pragma unroll
+  for (int i = 0; i < N; ++i) M[i * (i + 1) / 2 + i] = dadd ? M[i * (i + 1) / 2 + i] + dadd[i] : M[i * (i + 1) / 2 + i] * dmul;
   bool ok = (solver != 0);
   if (ok) {
     double dmax = 0.0;
 #pragma unroll
-    for (int i = 0; i < N; ++i) if (A[i * N + i] > dmax) dmax = A[i * N + i];
+    for (int i = 0; i < N; ++i) if (M[i * (i + 1) / 2 + i] > dmax) dmax = M[i * (i + 1) / 2 + i];
     const double tiny = 1e-13 * dmax;
     ok = dmax > 0.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      double d = A[j * N + j];
+      double d = M[j * (j + 1) / 2 + j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
+      for (int k = 0; k < j; ++k) d -= Lr[j * (j + 1) / 2 + k] * Lr[j * (j + 1) / 2 + k];
       if (!(d > tiny)) ok = false;
       // the diagonal holds 1 / L_jj: the substitutions below multiply (an fp64 division or square root is a
       // 10-20 instruction sequence on the solver's single dependency chain)
       const double idj = 1.0 / sqrt(d > tiny ? d : 1.0);
-      L[j * N + j] = idj;
+      Lr[j * (j + 1) / 2 + j] = idj;
 #pragma unroll
       for (int i = j + 1; i < N; ++i) {
-        double t = A[i * N + j];
+        double t = M[i * (i + 1) / 2 + j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) t -= L[i * N + k] * L[j * N + k];
-        L[i * N + j] = t * idj;
+        for (int k = 0; k < j; ++k) t -= Lr[i * (i + 1) / 2 + k] * Lr[j * (j + 1) / 2 + k];
+        Lr[i * (i + 1) / 2 + j] = t * idj;
       }
     }
   }
   if (!ok) {
-    // eigen-decomposition path (as published; also the ill-conditioned fallback): private copies,
-    // so that the arrays above never have their address taken
-    double A2[N * N], b2[N], x2[N], T[N * N], V[N * N], w[N];
-    for (int i = 0; i < N * N; ++i) A2[i] = A[i];
+    // eigen-decomposition path (as published; also the ill-conditioned fallback)
+    double A2[N * N], b2[N], x2[N], Tm[N * N], V[N * N], w[N];
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) A2[i * N + j] = (j <= i) ? M[i * (i + 1) / 2 + j] : M[j * (j + 1) / 2 + i];
     for (int i = 0; i < N; ++i) b2[i] = b[i];
-    sym_solve(N, A2, b2, x2, T, V, w);
+    sym_solve(N, A2, b2, x2, Tm, V, w);
     for (int i = 0; i < N; ++i) x[i] = x2[i];
     return;
   }
@@ -223,16 +240,21 @@ RCC_HD inline void spd_solve(int solver, const double* A, const double* b, doubl
   for (int i = 0; i < N; ++i) {            // L y = b
     double t = b[i];
 #pragma unroll
-    for (int k = 0; k < i; ++k) t -= L[i * N + k] * y[k];
-    y[i] = t * L[i * N + i];
+    for (int k = 0; k < i; ++k) t -= Lr[i * (i + 1) / 2 + k] * y[k];
+    y[i] = t * Lr[i * (i + 1) / 2 + i];
   }
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {       // L^T x = y
     double t = y[i];
 #pragma unroll
-    for (int k = i + 1; k < N; ++k) t -= L[k * N + i] * x[k];
-    x[i] = t * L[i * N + i];
+    for (int k = i + 1; k < N; ++k) t -= Lr[k * (k + 1) / 2 + i] * x[k];
+    x[i] = t * Lr[i * (i + 1) / 2 + i];
   }
+}
+template <int N>
+RCC_HD inline void spd_solve(int solver, const double* A, const double* b, double* x, double* /* workspace of the in-memory form: unused */)
+{
+  spd_solve_damped<N>(solver, A, (const double*)nullptr, 1.0, b, x);
 }
 
 // max_a (A^-1)[a][a] of a symmetric positive definite N x N matrix through its Cholesky factor: A^-1 = L^-T L^-1, so
@@ -240,28 +262,34 @@ RCC_HD inline void spd_solve(int solver, const double* A, const double* b, doubl
 // pivot says the matrix is numerically rank deficient (the caller then takes the eigen-decomposition, which drops
 // those directions as the published algorithm does).
 template <int N>
-RCC_HD inline int inv_diag_max_spd(const double* A, double* L /* N*N workspace */, double* maxdiag)
+RCC_HD inline int inv_diag_max_spd(const double* A, double* /* workspace of the in-memory form: unused */, double* maxdiag)
 {
+  constexpr int T = N * (N + 1) / 2;
+  double M[T], Lr[T];                      // lower triangles in registers (see spd_solve_damped)
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] = A[i * N + j];
   double dmax = 0.0;
 #pragma unroll
-  for (int i = 0; i < N; ++i) if (A[i * N + i] > dmax) dmax = A[i * N + i];
+  for (int i = 0; i < N; ++i) if (M[i * (i + 1) / 2 + i] > dmax) dmax = M[i * (i + 1) / 2 + i];
   if (!(dmax > 0.0)) return 0;
   const double tiny = 1e-13 * dmax;
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    double d = A[j * N + j];
+    double d = M[j * (j + 1) / 2 + j];
 #pragma unroll
-    for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
+    for (int k = 0; k < j; ++k) d -= Lr[j * (j + 1) / 2 + k] * Lr[j * (j + 1) / 2 + k];
     if (!(d > tiny)) ok = false;
     const double idj = 1.0 / sqrt(d > tiny ? d : 1.0);
-    L[j * N + j] = idj;                       // 1 / L_jj
+    Lr[j * (j + 1) / 2 + j] = idj;                       // 1 / L_jj
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
-      double t = A[i * N + j];
+      double t = M[i * (i + 1) / 2 + j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) t -= L[i * N + k] * L[j * N + k];
-      L[i * N + j] = t * idj;
+      for (int k = 0; k < j; ++k) t -= Lr[i * (i + 1) / 2 + k] * Lr[j * (j + 1) / 2 + k];
+      Lr[i * (i + 1) / 2 + j] = t * idj;
     }
   }
   if (!ok) return 0;
@@ -269,14 +297,14 @@ RCC_HD inline int inv_diag_max_spd(const double* A, double* L /* N*N workspace *
 #pragma unroll
   for (int a = 0; a < N; ++a) {
     double y[N];
-    y[a] = L[a * N + a];
+    y[a] = Lr[a * (a + 1) / 2 + a];
     double s = y[a] * y[a];
 #pragma unroll
     for (int k = a + 1; k < N; ++k) {
       double t = 0.0;
 #pragma unroll
-      for (int j = a; j < k; ++j) t -= L[k * N + j] * y[j];
-      y[k] = t * L[k * N + k];
+      for (int j = a; j < k; ++j) t -= Lr[k * (k + 1) / 2 + j] * y[j];
+      y[k] = t * Lr[k * (k + 1) / 2 + k];
       s += y[k] * y[k];
     }
     if (s > best) best = s;
@@ -293,28 +321,34 @@ RCC_HD inline int inv_diag_max_spd(const double* A, double* L /* N*N workspace *
 // takes this vector from a full eigen-decomposition (A.4); the vector is the same up to sign, and
 // the homography is normalised by H[2][2] afterwards.
 template <int N>
-RCC_HD inline int smallest_eigvec_psd(const double* M, double* x /* N */, double* L /* N*N workspace */)
+RCC_HD inline int smallest_eigvec_psd(const double* Min, double* x /* N */, double* /* workspace of the in-memory form: unused */)
 {
+  constexpr int T = N * (N + 1) / 2;
+  double M[T], Lr[T];                      // lower triangles in registers (see spd_solve_damped)
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) M[i * (i + 1) / 2 + j] = Min[i * N + j];
   double tr = 0.0;
 #pragma unroll
-  for (int i = 0; i < N; ++i) tr += M[i * N + i];
+  for (int i = 0; i < N; ++i) tr += M[i * (i + 1) / 2 + i];
   if (!(tr > 0.0)) return 0;
   const double delta = 1e-14 * tr;
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    double d = M[j * N + j] + delta;
+    double d = M[j * (j + 1) / 2 + j] + delta;
 #pragma unroll
-    for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
+    for (int k = 0; k < j; ++k) d -= Lr[j * (j + 1) / 2 + k] * Lr[j * (j + 1) / 2 + k];
     if (!(d > 0.0)) ok = false;
     const double idj = 1.0 / sqrt(d > 0.0 ? d : 1.0);
-    L[j * N + j] = idj;                       // the diagonal holds 1 / L_jj (see spd_solve)
+    Lr[j * (j + 1) / 2 + j] = idj;                       // the diagonal holds 1 / L_jj (see spd_solve_damped)
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
-      double t = M[i * N + j];
+      double t = M[i * (i + 1) / 2 + j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) t -= L[i * N + k] * L[j * N + k];
-      L[i * N + j] = t * idj;
+      for (int k = 0; k < j; ++k) t -= Lr[i * (i + 1) / 2 + k] * Lr[j * (j + 1) / 2 + k];
+      Lr[i * (i + 1) / 2 + j] = t * idj;
     }
   }
   if (!ok) return 0;
@@ -326,15 +360,15 @@ RCC_HD inline int smallest_eigvec_psd(const double* M, double* x /* N */, double
     for (int i = 0; i < N; ++i) {
       double t = x[i];
 #pragma unroll
-      for (int k = 0; k < i; ++k) t -= L[i * N + k] * x[k];
-      x[i] = t * L[i * N + i];
+      for (int k = 0; k < i; ++k) t -= Lr[i * (i + 1) / 2 + k] * x[k];
+      x[i] = t * Lr[i * (i + 1) / 2 + i];
     }
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
       double t = x[i];
 #pragma unroll
-      for (int k = i + 1; k < N; ++k) t -= L[k * N + i] * x[k];
-      x[i] = t * L[i * N + i];
+      for (int k = i + 1; k < N; ++k) t -= Lr[k * (k + 1) / 2 + i] * x[k];
+      x[i] = t * Lr[i * (i + 1) / 2 + i];
     }
     double nr = 0.0;
 #pragma unroll
@@ -667,26 +701,28 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
   const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
   double x[8], xd[8], v[8], d[8], Dg[8], tmp[8];
   double* const A = par.ws();                 // 64
-  double* const Ap = par.ws() + 64;           // 64
   double* const Lw = par.ws() + 128;          // 64: Cholesky factor
 #pragma unroll
   for (int i = 0; i < 8; ++i) x[i] = h[i];
   double rinf = 0.0;
+  RCC_PNP_TIC();
   double S = homography_accumulate(par, x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
+  RCC_PNP_TOC(0);
 #pragma unroll
   for (int i = 0; i < P; ++i) Dg[i] = A[i * P + i];
   const double Rlo = 0.25, Rhi = 0.75;
   double lambda = 1.0, lc = 0.75;
   int iter = 0;
   for (;;) {
+    double dadd[8];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) Ap[i] = A[i];
-#pragma unroll
-    for (int i = 0; i < P; ++i) Ap[i * P + i] += lambda * Dg[i];
-    spd_solve<8>(cm.solver, Ap, v, d, Lw);
+    for (int i = 0; i < P; ++i) dadd[i] = lambda * Dg[i];
+    spd_solve_damped<8>(cm.solver, A, dadd, 1.0, v, d);          // (A + lambda diag(Dg)) d = v
+    RCC_PNP_TOC(2);
 #pragma unroll
     for (int i = 0; i < P; ++i) xd[i] = x[i] - d[i];
     double Sd = homography_accumulate(par, xd, p, Rt, Tt, cm, has_dist, (double*)nullptr, (double*)nullptr, (double*)nullptr);
+    RCC_PNP_TOC(1);
     double dS = 0.0;
 #pragma unroll
     for (int a = 0; a < P; ++a) {
@@ -742,10 +778,12 @@ RCC_NI RCC_HD inline void homography_refine(const Par& par, double* h, const Pts
       }
       lambda *= nu;
     }
+    RCC_PNP_TOC(3);
     if (Sd < S) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) x[i] = xd[i];
       S = homography_accumulate(par, x, p, Rt, Tt, cm, has_dist, A, v, &rinf);
+      RCC_PNP_TOC(0);
     }
     ++iter;
     double dinf = 0.0;
@@ -956,14 +994,14 @@ RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* r
   double pprev[6], g[6], dl[6];
   double* const ws = par.ws();                // rebuilt here (not passed in) so that the address space is known: see WavePar
   double* const A = ws;                       // 36
-  double* const Ap = ws + 36;                 // 36
-  double* const Lw = ws + 72;                 // 36: Cholesky factor
   int L = -3, it = 0;
   double prevErr = 0.0;
   const int max_iter = 20;
   const double eps = FLT_EPSILON;
+  RCC_PNP_TIC();
   for (;;) {
     double S0 = accum(p, A, g);
+    RCC_PNP_TOC(4);
 #pragma unroll
     for (int a = 0; a < 6; ++a) pprev[a] = p[a];
     if (it == 0) prevErr = sqrt(S0);
@@ -973,14 +1011,12 @@ RCC_NI RCC_HD inline int pose_lm(double p[6], Accum accum, int solver, double* r
       const double p10[34] = { 1e-16, 1e-15, 1e-14, 1e-13, 1e-12, 1e-11, 1e-10, 1e-9, 1e-8, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1.0,
                                1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17 };
       double lambda = p10[(L < -16 ? -16 : (L > 17 ? 17 : L)) + 16];
-#pragma unroll
-      for (int i = 0; i < 36; ++i) Ap[i] = A[i];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) Ap[a * 6 + a] *= 1.0 + lambda;
-      spd_solve<6>(solver, Ap, g, dl, Lw);
+      spd_solve_damped<6>(solver, A, (const double*)nullptr, 1.0 + lambda, g, dl);     // diag * (1 + lambda)
+      RCC_PNP_TOC(6);
 #pragma unroll
       for (int a = 0; a < 6; ++a) p[a] = pprev[a] - dl[a];
       errNorm = sqrt(accum(p, (double*)nullptr, (double*)nullptr));
+      RCC_PNP_TOC(5);
       if (errNorm > prevErr) {
         if (++L <= 16) continue;
       }

@@ -16,7 +16,7 @@ for s0 in range(0, B, 64):
     det.synth_render(sp, poses[s0:s0 + 64], frames[s0:s0 + 64], first_index=s0)
 torch.cuda.synchronize()
 for _ in range(3): det.detect(frames, B, want_corners=False)
-tr = torch.zeros((B, 16), dtype=torch.int64, device="cuda:0")
+tr = torch.zeros((B, 24), dtype=torch.int64, device="cuda:0")
 torch.cuda.synchronize()
 det._L.rcc_debug_grid_trace.argtypes = [C.c_void_p, C.c_void_p]
 assert det._L.rcc_debug_grid_trace(det._h, C.c_void_p(tr.data_ptr())) == 0
@@ -38,6 +38,9 @@ print("kernel span (first start -> last end): %.1f us;  median end %.1f" % (end.
 seedatt = (t[:, 7] // 1000).astype(int)
 print("seed attempts histogram:", np.bincount(seedatt[ok]))
 print("pnp_iters histogram:", np.bincount(iters[ok]))
+for i, nm in enumerate(("H acc full", "H acc trial", "H solve8+copy", "H rest", "LM acc full", "LM acc trial", "LM solve6+copy")):
+    v = us(t[:, 16 + i])[ok]
+    print("   inner %-16s median %6.1f  max %6.1f us" % (nm, np.median(v), v.max()))
 print("H refinement iterations histogram:", np.bincount(t[:, 13].astype(int)[ok]))
 worst = np.argsort(-ph["total"] * ok)[:8]
 for f in worst:
