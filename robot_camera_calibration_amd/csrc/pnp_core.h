@@ -486,7 +486,13 @@ RCC_HD inline void rodrigues_v2m(const double r[3], double R[9], double* J /* 27
     }
     return;
   }
-  double c = cos(theta), s = sin(theta), c1 = 1.0 - c, it = 1.0 / theta;
+  double c, s;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(theta, &s, &c);          // one range reduction for both (the same values as sin() and cos())
+#else
+  c = cos(theta); s = sin(theta);
+#endif
+  double c1 = 1.0 - c, it = 1.0 / theta;
   double rx = r[0] * it, ry = r[1] * it, rz = r[2] * it;
   double rrt[9] = { rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz };
   double rxm[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };
@@ -517,6 +523,20 @@ RCC_HD inline void orthonormalise3(const double* M, double* Q)
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) MtM[i * 3 + j] = M[i] * M[j] + M[3 + i] * M[3 + j] + M[6 + i] * M[6 + j];
+  // A matrix that already is a rotation to rounding (a product of rotations, as at the end of the initial pose): the
+  // nearest rotation is M (M^T M)^(-1/2) = M (3 I - M^T M) / 2 + O(delta^2), delta = |M^T M - I| <= 1e-12 -- exact to the
+  // last bit that matters, without the eigen-decomposition (3 sweeps of 3 rotations, each a division and two square
+  // roots on the solver's single chain: ~6 us of the board pose).
+  double dev = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { const double e = fabs(MtM[i] - ((i % 4 == 0) ? 1.0 : 0.0)); dev = e > dev ? e : dev; }
+  if (dev <= 1e-12) {
+    double S1[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) S1[i] = ((i % 4 == 0) ? 1.5 : 0.0) - 0.5 * MtM[i];
+    mat3_mul(M, S1, Q);
+    return;
+  }
   jacobi_eigen_sym3(MtM, w, V);
   double S[9];
 #pragma unroll
