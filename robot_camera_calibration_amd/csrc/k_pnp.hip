@@ -99,13 +99,22 @@ __global__ __launch_bounds__(64) void k_pnp_board(const rcc_frame_corners* __res
   ndet[f] = 1;
 }
 
+// staging area of the matrix-core accumulation of the normal equations (WavePar::gram in pnp_core.h): an experiment that
+// lost to the vector path, compiled in only with -DRCC_PNP_GRAM
+#ifdef RCC_PNP_GRAM
+#define RCC_GRAM_STAGE(name) __shared__ double name[rccpnp::WavePar::GRAM_ROWS * rccpnp::WavePar::GRAM_STRIDE]
+#else
+#define RCC_GRAM_STAGE(name) double* const name = nullptr
+#endif
+__device__ __forceinline__ unsigned gram_lds(const double* p) { return p ? (unsigned)(uintptr_t)p : rccpnp::WavePar::GRAM_NONE; }
+
 // one wavefront per frame: pose of the board from its ordered corners.  XY(k, x, y) hands out corner k (row-major
 // lattice index); img: 2 * need doubles the solver reads its image points from (per frame, any memory)
 template <class XY>
 __device__ __forceinline__ void board_pose_frame(const int f, const int lane, XY xy_of, double* __restrict__ img,
                                                  const double* __restrict__ board_obj, int cols, int rows,
                                                  double square, int board_id, int reference_mode, const rcc_cam& cam,
-                                                 double* ws, rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
+                                                 double* ws, double* gram_stage, rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
 {
   const int need = cols * rows;
   for (int k = lane; k < need; k += 64) {
@@ -117,7 +126,7 @@ __device__ __forceinline__ void board_pose_frame(const int f, const int lane, XY
   }
   __syncthreads();
   rccpnp::Pts p{ board_obj, img, need };
-  rccpnp::WavePar par{ lane, (unsigned)(uintptr_t)ws };
+  rccpnp::WavePar par{ lane, (unsigned)(uintptr_t)ws, gram_lds(gram_stage) };
   double r[3], tv[3], e = 0.0;
   int it = 0;
   const int st = rccpnp::solve_pnp(par, p, to_cam(cam), cam.model, r, tv, &e, &it);
@@ -150,8 +159,9 @@ __global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* 
   const rcc_frame_corners* c = fc + f;
   if (c->status != 0 || c->ncorners != cols * rows) { if (lane == 0) ndet[f] = 0; return; }
   __shared__ double ws[rccpnp::PNP_WS];          // the wave-uniform matrices: one copy per wavefront, in LDS
+  RCC_GRAM_STAGE(gst);
   board_pose_frame(f, lane, [&](int k, double& x, double& y) { x = c->xy[k][0]; y = c->xy[k][1]; },
-                   img_scratch + (size_t)f * 2 * RCC_MAX_BOARD_CORNERS, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, det, ndet);
+                   img_scratch + (size_t)f * 2 * RCC_MAX_BOARD_CORNERS, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, gst, det, ndet);
 }
 
 // a6 + a7 of one frame in one wavefront: lattice indexing of the validated corners (grid_frame.h), then the pose from the
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* _
   __shared__ grid_smem sm;
   __shared__ double ws[rccpnp::PNP_WS];
   __shared__ double s_img[2 * RCC_MAX_BOARD_CORNERS];
+  RCC_GRAM_STAGE(gst);
   const int f = blockIdx.x;
   const int lane = threadIdx.x;
 #ifdef RCC_EXPERIMENTS
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* _
   GTRACE(5);
   if (!found) { if (lane == 0) ndet[f] = 0; return; }       // wave-uniform
   board_pose_frame(f, lane, [&](int k, double& x, double& y) { const int o = sm.order[k]; x = sm.xy[2 * o]; y = sm.xy[2 * o + 1]; },
-                   s_img, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, det, ndet);
+                   s_img, board_obj, cols, rows, square, board_id, reference_mode, cam, ws, gst, det, ndet);
   GTRACE(6);
 #ifdef RCC_EXPERIMENTS
   // slots 16..23 <- the category accumulators of the solver's inner steps
@@ -194,7 +205,8 @@ __global__ __launch_bounds__(64) void k_pnp_generic_wave(const double* __restric
   const int lane = threadIdx.x;
   rccpnp::Pts p{ obj + 3 * (size_t)off[t], img + 2 * (size_t)off[t], npts[t] };
   __shared__ double ws[rccpnp::PNP_WS];
-  rccpnp::WavePar par{ lane, (unsigned)(uintptr_t)ws };
+  RCC_GRAM_STAGE(gst);
+  rccpnp::WavePar par{ lane, (unsigned)(uintptr_t)ws, gram_lds(gst) };
   double r[3], tv[3], e = 0.0;
   int it = 0;
   int st = rccpnp::solve_pnp(par, p, to_cam(cam), cam.model, r, tv, &e, &it);

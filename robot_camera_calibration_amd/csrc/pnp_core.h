@@ -391,6 +391,9 @@ RCC_HD inline int smallest_eigvec_psd(const double* Min, double* x /* N */, doub
 enum { PNP_WS = 320 };   // [0,192) matrices and factors, [192,256) reduction totals, [256,320) normalised points (<= 64)
 struct SerialPar {
   double* w;
+  static constexpr bool kGram = false;       // no matrix-core accumulation for a single thread
+  RCC_HD bool gram_ok(int) const { return false; }
+  template <int NC, bool BORDER> RCC_HD void gram(const double*, const double*, int, double*, int, double*) const {}
   RCC_HD double* ws() const { return w; }
   RCC_HD int first() const { return 0; }
   RCC_HD int step() const { return 1; }
@@ -415,9 +418,72 @@ struct WavePar {
                      // address-space cast, so that inside the out-of-line solver routines the accesses compile to ds_*
                      // instructions: as a plain generic pointer they were FLAT operations, which go through the CU's
                      // vector-memory address path (16 cycles per wave instruction, shared by the four wavefronts of a CU)
+  unsigned g_lds;    // LDS byte offset of a GRAM_ROWS x GRAM_STRIDE-double staging area for the matrix-core accumulation (offset 0 is a valid one); GRAM_NONE: no area
   __device__ double* ws() const { return (double*)(__attribute__((address_space(3))) double*)(size_t)ws_lds; }
   __device__ int first() const { return lane; }
   __device__ int step() const { return 64; }
+
+  // ---- normal equations on the matrix cores (BASELINE.json north_star: "MFMA only for the small batched JtJ/Jtr
+  // normal-equation blocks of the PnP Gauss-Newton").  Every lane owns one point (n <= 64) and hands over its two rows
+  // g0, g1 of G = [J | e] (NC <= 10 columns); G^T G holds J^T J, J^T e and |e|^2.  v_mfma_f64_16x16x4_f64 computes a
+  // 16 x 16 product of depth 4 whose A operand (16 x 4: A[l & 15][l >> 4]) and B operand (4 x 16: B[l >> 4][l & 15]) are, for
+  // G^T G, the SAME register: lane l supplies G[4 s + (l >> 4)][l & 15] in step s (columns >= NC: zero).  2 n rows = n / 2
+  // instructions chained through one accumulator (24 for the 48-corner board) replace the 45 (28) products per lane and
+  // their 6-level recursive-halving reduction (~450 / 300 vector instructions on the solver's single chain).  The rows
+  // cross the lanes through an LDS staging area: 18 writes per lane, one contiguous 512-byte read per step.
+  // Result D[4 v + (l >> 4)][l & 15] in acc[v]: BORDER: the leading (NC-1) x (NC-1) block goes to dst (row stride dstride)
+  // and column NC-1 (J^T e, and |e|^2 last) to border[0..NC-1]; else the whole NC x NC matrix to dst.
+  enum { GRAM_ROWS = 128, GRAM_STRIDE = 10 };
+  static constexpr unsigned GRAM_NONE = 0xFFFFFFFFu;
+  static constexpr bool kGram = true;
+  // MEASURED, NOT KEPT: compiled in only with -DRCC_PNP_GRAM.  On the 48-corner board the pose got
+  // 18 us per frame SLOWER (95 -> 113 us median, scratch/t_grid_trace.py): gfx950 runs this instruction at 16 passes, so the
+  // 24 chained steps hold the wave for ~1500 cycles where the 180 vector instructions + 48 exchange steps they replace
+  // take about as many issue slots, and the rows' trip through LDS comes on top.
+#ifdef RCC_PNP_GRAM
+  __device__ bool gram_ok(int n) const { return g_lds != GRAM_NONE && n <= 64; }
+#else
+  __device__ bool gram_ok(int) const { return false; }
+#endif
+  template <int NC, bool BORDER>
+  __device__ __forceinline__ void gram(const double* g0, const double* g1, int nrows, double* dst, int dstride, double* border) const
+  {
+    static_assert(NC <= GRAM_STRIDE, "staging row too short");
+    typedef double v4d_t __attribute__((ext_vector_type(4)));
+    double* const G = (double*)(__attribute__((address_space(3))) double*)(size_t)g_lds;
+    double* const r0 = G + (2 * lane) * GRAM_STRIDE;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { r0[c] = g0[c]; r0[GRAM_STRIDE + c] = g1[c]; }
+    __syncthreads();
+    const int mi = lane & 15, mk = lane >> 4;
+    const double* const src = G + mk * GRAM_STRIDE + (mi < NC ? mi : 0);
+    v4d_t acc = { 0.0, 0.0, 0.0, 0.0 };
+    const int steps = (nrows + 3) >> 2;                        // wave-uniform; rows beyond nrows were written as zeros
+    for (int s0 = 0; s0 < steps; s0 += 8) {
+      double x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = (s0 + u < steps && mi < NC) ? src[(4 * (s0 + u)) * GRAM_STRIDE] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], x[u], acc, 0, 0, 0);
+    }
+    // acc[v] = D[4 v + mk][mi]
+    if (mi < NC) {
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const int row = 4 * v + mk;
+        if (row < NC) {
+          const double val = (v == 0) ? acc[0] : (v == 1) ? acc[1] : acc[2];
+          if (BORDER) {
+            if (mi < NC - 1 && row < NC - 1) dst[row * dstride + mi] = val;
+            if (mi == NC - 1) border[row] = val;
+          } else {
+            dst[row * dstride + mi] = val;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
   __device__ double sum(double v) const { return wred::all_sum(lane, v); }
   __device__ double max(double v) const {
 #pragma unroll
@@ -669,6 +735,34 @@ template <class Par>
 RCC_HD inline double homography_accumulate(const Par& par, const double* h, const Pts& p, const double* Rt, const double* Tt,
                                            const Cam& cm, bool has_dist, double* A, double* v, double* rinf)
 {
+  if constexpr (Par::kGram) {
+    if (A && par.gram_ok(p.n)) {
+      // one point per lane; its two rows of G = [J | r] go to the matrix cores (WavePar::gram)
+      double ga[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, gb[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+      double ri = 0.0;
+      const int i = par.first();
+      if (i < p.n) {
+        float Mxf, Myf, mxf, myf;
+        plane_point(p, i, Rt, Tt, Mxf, Myf);
+        norm_point(p, i, cm, has_dist, mxf, myf);
+        const double Mx = Mxf, My = Myf;
+        double ww = h[6] * Mx + h[7] * My + 1.0;
+        ww = fabs(ww) > DBL_EPSILON ? 1.0 / ww : 0.0;
+        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+        const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        const double e0 = xi - (double)mxf, e1 = yi - (double)myf;
+        ri = fabs(e0) > fabs(e1) ? fabs(e0) : fabs(e1);
+        ga[0] = Mx * ww; ga[1] = My * ww; ga[2] = ww; ga[6] = -Mx * ww * xi; ga[7] = -My * ww * xi; ga[8] = e0;
+        gb[3] = Mx * ww; gb[4] = My * ww; gb[5] = ww; gb[6] = -Mx * ww * yi; gb[7] = -My * ww * yi; gb[8] = e1;
+      }
+      if (rinf) *rinf = par.max(ri);
+      double* const red = par.ws() + 192;
+      par.template gram<9, true>(ga, gb, 2 * p.n, A, 8, red + 36);      // A = JtJ, red[36..43] = Jtr, red[44] = S
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = red[36 + r];
+      return red[44];
+    }
+  }
   // q[0..35]: this lane's share of JtJ (upper triangle, row-major), q[36..43]: of Jtr, q[44]: of S
   double q[45];
 #pragma unroll
@@ -850,9 +944,28 @@ RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const dou
   double invHnorm[9] = { 1.0 / smx, 0, cmx, 0, 1.0 / smy, cmy, 0, 0, 1 };
   double Hnorm2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
   double* const LtL = par.ws();               // 81
+  bool on_mfma = false;
+  if constexpr (Par::kGram) {
+    if (par.gram_ok(n)) {
+      double Lx[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, Ly[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+      const int i = par.first();
+      if (i < n) {
+        float Mxf, Myf, mxf, myf;
+        plane_point(p, i, Rt, Tt, Mxf, Myf);
+        norm_point(p, i, cm, has_dist, mxf, myf);
+        const double x = (mxf - cmx) * smx, y = (myf - cmy) * smy;
+        const double X = (Mxf - cMx) * sMx, Y = (Myf - cMy) * sMy;
+        Lx[0] = X; Lx[1] = Y; Lx[2] = 1; Lx[6] = -x * X; Lx[7] = -x * Y; Lx[8] = -x;
+        Ly[3] = X; Ly[4] = Y; Ly[5] = 1; Ly[6] = -y * X; Ly[7] = -y * Y; Ly[8] = -y;
+      }
+      par.template gram<9, false>(Lx, Ly, 2 * n, LtL, 9, (double*)nullptr);   // L^T L, the whole 9 x 9 matrix
+      on_mfma = true;
+    }
+  }
   double ll[45];                              // this lane's share, upper triangle row-major
 #pragma unroll
   for (int i = 0; i < 45; ++i) ll[i] = 0.0;
+  if (!on_mfma) {
   for (int i = par.first(); i < n; i += par.step()) {
     float Mxf, Myf, mxf, myf;
     plane_point(p, i, Rt, Tt, Mxf, Myf);
@@ -869,6 +982,7 @@ RCC_NI RCC_HD inline int find_homography(const Par& par, const Pts& p, const dou
   par.template reduce_store<32>(ll, par.ws() + 192);
   par.template reduce_store<13>(ll + 32, par.ws() + 192 + 32);
   par.template unpack_sym<9>(par.ws() + 192, LtL);
+  }
   double H0[9], T[9];
   if (!(cm.solver == 1 && smallest_eigvec_psd<9>(LtL, H0, par.ws() + 81))) {
     double* const L2 = LtL;                           // full decomposition (as published / fallback), in place
@@ -898,6 +1012,22 @@ RCC_HD inline double pose_accumulate(const Par& par, const double* prm, const Pt
 {
   double R[9], dRdr[27];
   rodrigues_v2m(prm, R, A ? dRdr : nullptr);
+  if constexpr (Par::kGram) {
+    if (A && par.gram_ok(p.n)) {
+      double gu[7] = { 0, 0, 0, 0, 0, 0, 0 }, gv[7] = { 0, 0, 0, 0, 0, 0, 0 };
+      const int i = par.first();
+      if (i < p.n) {
+        double uv[2];
+        project_point(p.obj + 3 * i, R, dRdr, prm + 3, cm, uv, gu, gv);      // the two Jacobian rows straight into G
+        gu[6] = uv[0] - p.img[2 * i]; gv[6] = uv[1] - p.img[2 * i + 1];
+      }
+      double* const red = par.ws() + 192;
+      par.template gram<7, true>(gu, gv, 2 * p.n, A, 6, red + 21);            // A = JtJ, red[21..26] = Jte, red[27] = S
+#pragma unroll
+      for (int a = 0; a < 6; ++a) g[a] = red[21 + a];
+      return red[27];
+    }
+  }
   // q[0..20]: this lane's share of JtJ (upper triangle, row-major), q[21..26]: of Jte, q[27]: of S
   double q[28];
 #pragma unroll

@@ -3,7 +3,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["RCC_LIBRARY"] = os.path.join(ROOT, "robot_camera_calibration_amd", "librcc_hip_exp.so")
+os.environ["RCC_LIBRARY"] = os.path.join(ROOT, "robot_camera_calibration_amd", os.environ.get("RCC_EXP_LIB", "librcc_hip_exp.so"))
 import ctypes as C
 import numpy as np, torch
 from robot_camera_calibration_amd import abi, api, synth
