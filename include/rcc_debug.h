@@ -93,6 +93,9 @@ int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void
  * 16..23 = time spent in: H accumulate (full), H accumulate (trial), H 8x8 solve, H rest, pose accumulate (full), pose accumulate (trial),
  * pose 6x6 solve, (unused);
  * NULL switches it off. */
+/* experiment: the wave-per-window threshold + corner pass reads the grey rows of frame (f mod m) -- a working set small enough
+ * to stay in the Infinity Cache; m = 0: off.  Results are then those of the wrong frames. */
+int rcc_set_dense_fmod(rcc_handle* h, int32_t m);
 int rcc_debug_grid_trace(rcc_handle* h, void* d_buf);
 #endif
 

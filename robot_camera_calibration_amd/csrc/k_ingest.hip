@@ -174,6 +174,53 @@ static rcc_cam make_cam(const rcc_config& c)
   return k;
 }
 
+hipError_t rcc_ingest_staged_plan(rcc_handle* h, const uint8_t* d_frames, int nframes, hipStream_t s, rcc_ingest_plan* p, bool* staged)
+{
+  const rcc_config& c = h->cfg;
+  const int w = c.width, ht = c.height;
+  *staged = false;
+  if (!h->undist || nframes <= 0) return hipSuccess;
+  int variant = h->ingest_variant;
+  const bool staged_ok = ((w % ST_TW) == 0) && ((ht % ST_TH) == 0) && ((c.stride_bytes & 15) == 0) && ((c.frame_bytes & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0);
+  if (variant < 0) variant = staged_ok ? 1 : 0;
+  if (variant != 1 || !staged_ok) return hipSuccess;
+  p->cam = make_cam(c);
+#ifdef RCC_EXPERIMENTS
+  static const int fpb_max = getenv("RCC_INGEST_FPB") ? atoi(getenv("RCC_INGEST_FPB")) : 32;
+#else
+  const int fpb_max = 32;
+#endif
+  int fpb = fpb_max;
+  const int tiles = ((w + ST_TW - 1) / ST_TW) * ((ht + ST_TH - 1) / ST_TH);
+  while (fpb > 2 && (int64_t)tiles * ((nframes + fpb - 1) / fpb) < 4096) fpb >>= 1;
+  p->fpb = fpb; p->tiles = tiles;
+  p->ntx = (w + ST_TW - 1) / ST_TW; p->per_xcd = (tiles + 7) / 8; p->ngroups = (nframes + fpb - 1) / fpb;
+  if (!h->d_map && !h->map_failed) {
+    // first staged launch of this handle: tabulate the map (w * h * 8 B) and the tiles' source boxes
+    if (hipMalloc((void**)&h->d_map, (size_t)w * ht * sizeof(int2)) != hipSuccess || hipMalloc((void**)&h->d_tilebox, (size_t)tiles * sizeof(int4)) != hipSuccess) {
+      if (h->d_map) (void)hipFree(h->d_map);
+      h->d_map = nullptr; h->d_tilebox = nullptr; h->map_failed = 1;      // no room: the kernel recomputes the map itself
+      (void)hipGetLastError();
+    } else {
+      hipLaunchKernelGGL(k_ingest_map, dim3(tiles), dim3(256), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
+      hipError_t em = hipGetLastError();
+      if (em == hipSuccess) em = hipStreamSynchronize(s);      // once per handle: later launches may come on other streams
+      if (em != hipSuccess) {
+        // tables that may not have been written must never be read: drop them, the kernel recomputes the map per block
+        (void)hipFree(h->d_map); (void)hipFree(h->d_tilebox);
+        h->d_map = nullptr; h->d_tilebox = nullptr; h->map_failed = 1;
+        return em;
+      }
+    }
+  }
+  p->map = h->ingest_table ? h->d_map : nullptr;
+  p->tilebox = h->ingest_table ? h->d_tilebox : nullptr;
+  if (!p->map || !p->tilebox) { p->map = nullptr; p->tilebox = nullptr; }
+  *staged = true;
+  return hipSuccess;
+}
+
 hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes, uint8_t* d_grey, hipStream_t s)
 {
   const rcc_config& c = h->cfg;
@@ -198,49 +245,23 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
     }
     return hipGetLastError();
   }
-  rcc_cam cam = make_cam(c);
-  int variant = h->ingest_variant;
-  const bool staged_ok = ((w % ST_TW) == 0) && ((ht % ST_TH) == 0) && ((c.stride_bytes & 15) == 0) && ((c.frame_bytes & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0);
-  if (variant < 0) variant = staged_ok ? 1 : 0;
-  if (variant == 1 && staged_ok) {
-#ifdef RCC_EXPERIMENTS
-    static const int fpb_max = getenv("RCC_INGEST_FPB") ? atoi(getenv("RCC_INGEST_FPB")) : 32;
-#else
-    const int fpb_max = 32;
-#endif
-    int fpb = fpb_max;
-    const int tiles = ((w + ST_TW - 1) / ST_TW) * ((ht + ST_TH - 1) / ST_TH);
-    while (fpb > 2 && (int64_t)tiles * ((nframes + fpb - 1) / fpb) < 4096) fpb >>= 1;
-    const int ntx = (w + ST_TW - 1) / ST_TW, per_xcd = (tiles + 7) / 8, ngroups = (nframes + fpb - 1) / fpb;
-    if (!h->d_map && !h->map_failed) {
-      // first staged launch of this handle: tabulate the map (w * h * 8 B) and the tiles' source boxes
-      if (hipMalloc((void**)&h->d_map, (size_t)w * ht * sizeof(int2)) != hipSuccess || hipMalloc((void**)&h->d_tilebox, (size_t)tiles * sizeof(int4)) != hipSuccess) {
-        if (h->d_map) (void)hipFree(h->d_map);
-        h->d_map = nullptr; h->d_tilebox = nullptr; h->map_failed = 1;      // no room: the kernel recomputes the map itself
-        (void)hipGetLastError();
-      } else {
-        hipLaunchKernelGGL(k_ingest_map, dim3(tiles), dim3(256), 0, s, w, ht, cam, ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
-        hipError_t em = hipGetLastError();
-        if (em == hipSuccess) em = hipStreamSynchronize(s);      // once per handle: later launches may come on other streams
-        if (em != hipSuccess) {
-          // tables that may not have been written must never be read: drop them, the kernel recomputes the map per block
-          (void)hipFree(h->d_map); (void)hipFree(h->d_tilebox);
-          h->d_map = nullptr; h->d_tilebox = nullptr; h->map_failed = 1;
-          return em;
-        }
-      }
+  {
+    rcc_ingest_plan p;
+    bool staged = false;
+    hipError_t e = rcc_ingest_staged_plan(h, d_frames, nframes, s, &p, &staged);
+    if (e != hipSuccess) return e;
+    if (staged) {
+      dim3 grid(8 * p.per_xcd * p.ngroups);
+      if (c.pixfmt == RCC_PIX_BGR8)
+        hipLaunchKernelGGL((k_ingest_staged<3>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, p.cam, d_grey, nframes, p.fpb, p.ntx, p.tiles, p.per_xcd,
+                           (const int2*)p.map, (const int4*)p.tilebox);
+      else
+        hipLaunchKernelGGL((k_ingest_staged<1>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, p.cam, d_grey, nframes, p.fpb, p.ntx, p.tiles, p.per_xcd,
+                           (const int2*)p.map, (const int4*)p.tilebox);
+      return hipGetLastError();
     }
-    const int2* mp = h->ingest_table ? (const int2*)h->d_map : nullptr;
-    const int4* tb = h->ingest_table ? (const int4*)h->d_tilebox : nullptr;
-    if (!mp || !tb) { mp = nullptr; tb = nullptr; }
-    dim3 grid(8 * per_xcd * ngroups);
-    if (c.pixfmt == RCC_PIX_BGR8)
-      hipLaunchKernelGGL((k_ingest_staged<3>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb, ntx, tiles, per_xcd, mp, tb);
-    else
-      hipLaunchKernelGGL((k_ingest_staged<1>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb, ntx, tiles, per_xcd, mp, tb);
-    return hipGetLastError();
   }
+  rcc_cam cam = make_cam(c);
   // frames per block: amortise the fp64 map; keep >= ~2048 blocks in flight
   int fpb = 16;
   const int tiles = ((w + 255) / 256) * ((ht + 3) / 4);

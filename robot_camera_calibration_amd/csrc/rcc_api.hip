@@ -836,6 +836,12 @@ int rcc_time_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes,
 }
 
 #ifdef RCC_EXPERIMENTS
+int rcc_set_dense_fmod(rcc_handle* h, int m)
+{
+  if (!h || m < 0) return RCC_ERR_ARG;
+  h->dense_fmod = m;
+  return RCC_OK;
+}
 // experiment: per-frame phase time stamps of k_grid_pnp (8 x int64 per frame, wall_clock64 ticks of 10 ns): NULL switches off
 hipError_t rcc_set_grid_trace(long long* d_buf);
 int rcc_debug_grid_trace(rcc_handle* h, void* d_buf)
@@ -847,7 +853,8 @@ int rcc_debug_grid_trace(rcc_handle* h, void* d_buf)
   return RCC_OK;
 }
 // experiment: do the ingest pass (bandwidth-bound) and the threshold+corner pass (issue-bound) overlap when they are
-// launched on two streams over independent buffers?  mode 0: back to back on one stream; 1: concurrently.
+// launched on two streams over independent buffers?  mode 0: back to back on one stream; 1: concurrently on two streams;
+// 2: as two roles of one launch (k_mix.hip); 3 / 4: the ingest / the threshold+corner pass alone.
 int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,
                       void* d_cand, void* d_cand_count, int32_t mode, int32_t reps, float* mean_ms)
 {
@@ -859,10 +866,18 @@ int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void
   HIPCHK(h, hipStreamSynchronize(s));
   HIPCHK(h, hipEventRecord(h->ev[6], s));
   for (int r = 0; r < reps; ++r) {
-    if (mode == 0) {
-      HIPCHK(h, rcc_launch_ingest(h, (const uint8_t*)d_frames, nframes, (uint8_t*)d_grey_out, s));
+    HIPCHK(h, hipMemsetAsync(d_cand_count, 0, sizeof(int32_t) * (size_t)nframes, s));
+    if (mode == 0 || mode == 3 || mode == 4) {
+      // 0: back to back; 3: the ingest pass alone; 4: the threshold + corner pass alone
+      if (mode != 4) HIPCHK(h, rcc_launch_ingest(h, (const uint8_t*)d_frames, nframes, (uint8_t*)d_grey_out, s));
       h->want_thr = 1;
-      HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey_in, nframes, h->d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, s));
+      if (mode != 3) HIPCHK(h, rcc_launch_dense(h, (const uint8_t*)d_grey_in, nframes, h->d_bin, (rcc_cand*)d_cand, (int32_t*)d_cand_count, s));
+    } else if (mode == 2) {
+      // both passes as roles of one launch (k_mix.hip)
+      bool done = false;
+      HIPCHK(h, rcc_launch_mix(h, (const uint8_t*)d_frames, nframes, (uint8_t*)d_grey_out, (const uint8_t*)d_grey_in, nframes, h->d_thr,
+                               (rcc_cand*)d_cand, (int32_t*)d_cand_count, s, &done));
+      if (!done) return RCC_ERR_ARG;
     } else {
       HIPCHK(h, hipEventRecord(h->pev[0], s));
       HIPCHK(h, hipStreamWaitEvent(a, h->pev[0], 0));

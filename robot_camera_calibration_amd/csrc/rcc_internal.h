@@ -112,6 +112,7 @@ struct rcc_handle {
   int host_chunk_frames;    // 0: automatic (about 192 MiB per chunk); > 0: frames per chunk; < 0: one copy of the whole batch, then the kernels
   int pipeline_chunks;      // 0/1: one pass over the whole batch on one stream; n > 1: n chunks alternating over two streams
   int dense_variant, ingest_variant;
+  int dense_fmod;           // experiments only (rcc_set_dense_fmod): the pass reads the grey rows of frame f mod this; 0 off
   int dense_gang_sync;      // k_dense_wave: 0 = every window its own workgroup; n (a power of two) = gangs of eight windows meeting every n tile rows
   int dense_gang_seg;       // segments per frame of the gang form (0: as the single-window form)
   int dense_skip;           // 1: the fast dense kernel may skip flat wave-rows (exact); 0: never (A/B, tests)
@@ -128,6 +129,24 @@ struct rcc_handle {
 
 // ---- launchers (each returns hipError_t of the launch) ---------------------------------------
 hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes, uint8_t* d_grey, hipStream_t s);
+// launch geometry of the staged undistort + grey pass (k_ingest.hip) and of the wave-per-window threshold + corner pass
+// (k_dense_wave.hip), worked out by the files that own the kernels and shared with the launch that runs both side by side (k_mix.hip)
+struct rcc_ingest_plan {
+  rcc_cam cam;
+  int fpb, ntx, tiles, per_xcd, ngroups;     // frames per workgroup, tiles per row, tiles, tiles per XCD, frame groups
+  const void* map; const void* tilebox;      // the tabulated Q5 map and the tiles' source boxes (null: recomputed per workgroup)
+};
+struct rcc_wave_plan {
+  int nbands, nwin, nseg, seg_tiles, fchunk;
+  long long njobs;                            // single-wavefront jobs, padded to whole deals (dense_wave_body.h)
+};
+// *staged = false: this configuration does not take the staged form (nothing else is filled in)
+hipError_t rcc_ingest_staged_plan(rcc_handle* h, const uint8_t* d_frames, int nframes, hipStream_t s, rcc_ingest_plan* p, bool* staged);
+void rcc_dense_wave_plan(const rcc_handle* h, int nframes, rcc_wave_plan* p);
+// ingest of frames [0, n_in) of d_frames -> d_grey_out beside the threshold + corner pass of the n_dn frames at d_grey_in (an earlier
+// chunk of the batch), one launch; either count may be 0.  *done = false: not applicable here, nothing was launched
+hipError_t rcc_launch_mix(rcc_handle* h, const uint8_t* d_frames, int n_in, uint8_t* d_grey_out,
+                          const uint8_t* d_grey_in, int n_dn, uint8_t* d_thr, rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s, bool* done);
 bool rcc_dense_wave_supported(const rcc_handle* h, const uint8_t* d_grey);
 hipError_t rcc_launch_dense_wave(rcc_handle* h, const uint8_t* d_grey, int nframes, rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s);
 hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8_t* d_bin,

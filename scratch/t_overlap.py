@@ -1,5 +1,6 @@
 # experiment: ingest and threshold+corner pass launched together on two streams (independent buffers) vs back to back
 import os, sys, ctypes as C
+os.environ.setdefault("RCC_LIBRARY", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "robot_camera_calibration_amd", "librcc_hip_exp.so"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from robot_camera_calibration_amd import abi, api, synth
@@ -18,7 +19,24 @@ torch.cuda.synchronize()
 det.stage_ingest(frames, B, g2)
 L = det._L
 L.rcc_debug_overlap.argtypes = [C.c_void_p] * 2 + [C.c_int32] + [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.POINTER(C.c_float)]
-for mode in (0, 1, 0, 1):
+FMOD = int(os.environ.get("FMOD", "0"))
+if FMOD:
+    L.rcc_set_dense_fmod.argtypes = [C.c_void_p, C.c_int32]
+    print("dense pass reads frame f mod", FMOD, "->", L.rcc_set_dense_fmod(det._h, FMOD))
+names = {0: "back to back", 1: "two streams", 2: "one launch, two roles (k_mix)", 3: "ingest alone", 4: "dense alone"}
+ref = None
+for mode in (3, 4, 0, 2, 1, 0, 2, 3, 4):
     ms = C.c_float(0)
+    g1.zero_()
     st = L.rcc_debug_overlap(det._h, api._ptr(frames), B, api._ptr(g1), api._ptr(g2), api._ptr(cand), api._ptr(cnt), mode, 5, C.byref(ms))
-    print("mode", mode, "status", st, "ms per (ingest + dense)", round(ms.value, 3))
+    torch.cuda.synchronize()
+    out = (int(cnt.sum().item()), bool(torch.equal(g1, g2)))
+    print("mode", mode, names[mode], "status", st, "ms per repetition", round(ms.value, 3), "candidates", out[0], "grey == reference grey", out[1], flush=True)
+    if mode == 0 and ref is None:
+        ref = (cnt.clone(), cand.clone())
+    if mode == 2 and ref is not None:
+        # candidate lists: same counts per frame; entries are appended by atomics, so compare them as sets per frame
+        same = bool(torch.equal(cnt, ref[0]))
+        a = cand.view(B, -1, 8)[:, :64].contiguous().view(torch.int64).sort(dim=1).values
+        b = ref[1].view(B, -1, 8)[:, :64].contiguous().view(torch.int64).sort(dim=1).values
+        print("   k_mix vs back to back: counts equal", same, "first 64 entries per frame equal as sets", bool(torch.equal(a, b)))
