@@ -152,7 +152,7 @@ def wave_listing():
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not found")
     out = os.path.join(CSRC, "k_dense_wave.isa.s")
-    deps = [os.path.join(CSRC, f) for f in ("k_dense_wave.hip", "dense_band_body.h", "dense_rows.h", "rcc_internal.h")]
+    deps = [os.path.join(CSRC, f) for f in ("k_dense_wave.hip", "dense_wave_body.h", "dense_band_body.h", "dense_rows.h", "rcc_internal.h")]
     if not os.path.exists(out) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(out):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
                                "-o", out, os.path.join(CSRC, "k_dense_wave.hip")], stderr=subprocess.DEVNULL)
@@ -164,7 +164,7 @@ def test_counted_wait_invariant_holds_in_the_compiled_wave_kernel(wave_listing):
     That needs, per unrolled iteration and on every path: the wait, then the LDS-DMA of the row WAVE_DEPTH ahead as the
     first vector-memory operation, and ONE byte store of the tile levels after the corner stages have rejoined (more
     operations -- the candidate path -- only make the wait stricter; fewer would let it pass early)."""
-    src = open(os.path.join(CSRC, "k_dense_wave.hip")).read()
+    src = open(os.path.join(CSRC, "dense_wave_body.h")).read()
     depth = int(re.search(r"#define\s+WAVE_DEPTH\s+(\d+)", src).group(1))
     want_wait = "s_waitcnt vmcnt(%d) lgkmcnt(0)" % (2 * depth - 1)
     kernels = _kernels(wave_listing, "k_dense_wave")
