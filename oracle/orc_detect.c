@@ -99,14 +99,23 @@ int orc_ctx_detect(orc_ctx* c, const uint8_t* frame, int frame_index, rcc_detect
   if (pre_out) memcpy(pre_out, c->pre, sizeof(orc_cand) * (size_t)npre);
   double* pxy = c->pxy;
   double xy[2 * 256];
-  const int tag_edges = (cfg->target_kind == RCC_TARGET_FIDUCIAL) && (cfg->tag_refine == RCC_TAG_REFINE_EDGES);
-  if (tag_edges) {
-    /* refine_edges form: the a5 pass only has to bring a candidate within a pixel of its corner (classification and linking
-     * work on rounded positions; the reported corners come from the edges): at most RCC_TAG_COARSE_ITERS iterations, stop below
-     * RCC_TAG_COARSE_EPS px */
-    const int it = cfg->subpix_max_iter < RCC_TAG_COARSE_ITERS ? cfg->subpix_max_iter : RCC_TAG_COARSE_ITERS;
-    const double eps = cfg->subpix_eps > RCC_TAG_COARSE_EPS ? cfg->subpix_eps : RCC_TAG_COARSE_EPS;
-    orc_corner_subpix(c->grey, w, h, c->pre, npre, cfg->subpix_win, it, eps, pxy);
+  if (cfg->target_kind == RCC_TARGET_FIDUCIAL) {
+    /* Square fiducials: only what can become a quad corner is refined.  A candidate whose own pixel does not pass the
+     * convex-black-corner test (orc_fid_corner_class, the test the quad stage applies to the rounded refined position) keeps
+     * that pixel as its position -- where the quad stage's test fails for it again, so it can neither be a corner nor
+     * attract a link.  About two thirds of a tag scene's candidates (the payload's inner corners) go this way.
+     * refine_edges form: the a5 pass of the others only has to bring them within a pixel of their corner (classification
+     * and linking work on rounded positions; the reported corners come from the edges): at most RCC_TAG_COARSE_ITERS
+     * iterations, stop below RCC_TAG_COARSE_EPS px.  cornerSubPix form: the configured iteration limits. */
+    const int tag_edges = (cfg->tag_refine == RCC_TAG_REFINE_EDGES);
+    const int it = (tag_edges && cfg->subpix_max_iter > RCC_TAG_COARSE_ITERS) ? RCC_TAG_COARSE_ITERS : cfg->subpix_max_iter;
+    const double eps = (tag_edges && cfg->subpix_eps < RCC_TAG_COARSE_EPS) ? RCC_TAG_COARSE_EPS : cfg->subpix_eps;
+    for (int i = 0; i < npre; ++i) {
+      int a[2], b[2], t;
+      if (orc_fid_corner_class(c->grey, w, h, c->pre[i].x, c->pre[i].y, cfg->thr_min_contrast, a, b, &t))
+        orc_corner_subpix(c->grey, w, h, c->pre + i, 1, cfg->subpix_win, it, eps, pxy + 2 * i);
+      else { pxy[2 * i] = (double)c->pre[i].x; pxy[2 * i + 1] = (double)c->pre[i].y; }
+    }
   } else {
     orc_corner_subpix(c->grey, w, h, c->pre, npre, cfg->subpix_win, cfg->subpix_max_iter, cfg->subpix_eps, pxy);
   }

@@ -251,6 +251,15 @@ def fid_refine_edges(grey, qi):
     return out.reshape(4, 2)
 
 
+def fid_corner_class(grey, pts, min_contrast):
+    """convex-black-corner test of the fiducial stages at integer pixels pts (N x 2: x, y); N booleans"""
+    h, w = grey.shape
+    g = np.ascontiguousarray(grey, np.uint8)
+    a, b, t = (C.c_int * 2)(), (C.c_int * 2)(), C.c_int(0)
+    f = lib().orc_fid_corner_class
+    return np.array([bool(f(_p(g), C.c_int(w), C.c_int(h), C.c_int(int(x)), C.c_int(int(y)), C.c_int(min_contrast), a, b, C.byref(t))) for x, y in pts])
+
+
 def synth_render(cfg, sp, pose, frame_index):
     ch = 3 if cfg.pixfmt == abi.RCC_PIX_BGR8 else 1
     out = np.zeros((cfg.height, cfg.stride_bytes), np.uint8)

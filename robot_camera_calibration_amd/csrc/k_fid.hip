@@ -61,15 +61,19 @@ __device__ bool fid_corner_class(const uint8_t* __restrict__ g, int w, int h, in
   return true;
 }
 
-// all 16 probes are loaded before any is tested: one memory latency instead of up to eight dependent ones
-// (the decision is unchanged: false if any probe leaves the image, else at least 7 of 8 two-sided probes good)
-__device__ bool fid_edge_ok(const uint8_t* __restrict__ g, int w, int h, int xi, int yi, int wx, int wy, int nx, int ny, int t)
+// The segment test of the link stage: 8 two-sided probes along the segment (black on the n side, white on the other), good
+// if no probe leaves the image and at least 7 of the 8 are right.  Evaluated in two parts -- first the probes of FID_S1,
+// then the rest -- because almost every pair the link stage tries is wrong and fails both probes of the first part, after
+// which 7 of 8 cannot be reached: a quarter of the (scattered, one byte per lane) loads decides most pairs.  Within a
+// part all loads are issued before any is tested.
+template <unsigned MASK>
+__device__ __forceinline__ void fid_edge_part(const uint8_t* __restrict__ g, int w, int h, int xi, int yi, int wx, int wy, int ox, int oy, int t,
+                                              bool& inb, int& good)
 {
-  const int ox = fid_rdiv10(nx), oy = fid_rdiv10(ny);
-  bool inb = true;
   int vb[8], vc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
+    if (!((MASK >> k) & 1u)) continue;
     const int mx = (xi * 16 + wx * (2 * k + 1) + 8) >> 4, my = (yi * 16 + wy * (2 * k + 1) + 8) >> 4;
     const int bx = mx + ox, by = my + oy, cx = mx - ox, cy = my - oy;
     const bool ok = !(bx < 0 || by < 0 || bx >= w || by >= h || cx < 0 || cy < 0 || cx >= w || cy >= h);
@@ -78,9 +82,25 @@ __device__ bool fid_edge_ok(const uint8_t* __restrict__ g, int w, int h, int xi,
     vb[k] = g[(size_t)byc * w + bxc];
     vc[k] = g[(size_t)cyc * w + cxc];
   }
-  int good = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) good += (vb[k] <= t && vc[k] > t) ? 1 : 0;
+  for (int k = 0; k < 8; ++k)
+    if ((MASK >> k) & 1u) good += (vb[k] <= t && vc[k] > t) ? 1 : 0;
+}
+#define FID_S1 0x42u          // probes 1 and 6 of 8 (3/16 and 13/16 along the segment)
+#define FID_S2 (0xFFu & ~FID_S1)
+// first part: can the pair still pass?  (false: a probe left the image, or both probes are wrong -- at most 6 of 8 remain)
+__device__ __forceinline__ bool fid_edge_first(const uint8_t* __restrict__ g, int w, int h, int xi, int yi, int wx, int wy, int nx, int ny, int t, int& good1)
+{
+  bool inb = true;
+  good1 = 0;
+  fid_edge_part<FID_S1>(g, w, h, xi, yi, wx, wy, fid_rdiv10(nx), fid_rdiv10(ny), t, inb, good1);
+  return inb && good1 >= 1;
+}
+__device__ __forceinline__ bool fid_edge_rest(const uint8_t* __restrict__ g, int w, int h, int xi, int yi, int wx, int wy, int nx, int ny, int t, int good1)
+{
+  bool inb = true;
+  int good = good1;
+  fid_edge_part<FID_S2>(g, w, h, xi, yi, wx, wy, fid_rdiv10(nx), fid_rdiv10(ny), t, inb, good);
   return inb && good >= 7;
 }
 
@@ -390,7 +410,7 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
   __shared__ int s_nc, s_nq;
   const int f = blockIdx.x, tid = threadIdx.x;
 #ifdef RCC_FID_TRACE
-  long long tk[8]; int tki = 0;
+  long long tk[12]; int tki = 0;
 #define FID_TICK() do { __syncthreads(); tk[tki++] = wall_clock64(); } while (0)
 #else
 #define FID_TICK() do {} while (0)
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
   const int nc = s_nc;
   FID_TICK();
   // phase 2: link along d1 (black on the (-dy, dx) side of the direction of travel).  The specification: among the corners
-  // j that pass the integer gates (distance, direction, cone) AND whose connecting segment verifies (fid_edge_ok), the
+  // j that pass the integer gates (distance, direction, cone) AND whose connecting segment verifies (fid_edge_first + fid_edge_rest), the
   // nearest one, ties to the smallest index.  The verification reads 16 pixels; done inside the scan it ran whenever any
   // lane of the wave had a candidate (a memory latency per scan step).  So: (A) a pure-ALU scan over the packed compact
   // positions (one 16-byte LDS read per 4 corners) keeps the FK nearest gate-passers in (distance, index) order; (B) they
@@ -498,17 +518,28 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
         }
       }
     }
+    FID_TICK();     // (trace builds only; nc <= 256: the loop runs once)
     // (B) all FK probes are made unconditionally (an empty slot probes the corner against itself), so that the 16 FK loads
     // are in flight together; the first good one in (distance, index) order is the link
     bool okq[FK];
+    int g1[FK], ewx[FK], ewy[FK];
 #pragma unroll
     for (int q = 0; q < FK; ++q) {
       const uint32_t e = cj[q] >= 0 ? s_pk[cj[q]] : pki;
-      okq[q] = fid_edge_ok(g, w, h, xi, yi, (int)(e & 0xFFFFu) - xi, (int)(e >> 16) - yi, -dy, dx, t);
+      ewx[q] = (int)(e & 0xFFFFu) - xi; ewy[q] = (int)(e >> 16) - yi;
+      okq[q] = fid_edge_first(g, w, h, xi, yi, ewx[q], ewy[q], -dy, dx, t, g1[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < FK; ++q) {
+      if (__any(okq[q])) {                               // wave-uniform: the other twelve loads only where some lane still needs them
+        const bool r = fid_edge_rest(g, w, h, xi, yi, ewx[q], ewy[q], -dy, dx, t, g1[q]);
+        okq[q] = okq[q] && r;
+      }
     }
     int best = -1;
 #pragma unroll
     for (int q = FK - 1; q >= 0; --q) if (act && cj[q] >= 0 && okq[q]) best = cj[q];
+    FID_TICK();
     // (C) every remaining passer has to be probed (the nearest good one wins): corners of the code pattern pass the gates
     // with 25-100 others and link to none.  Probing inside the scan cost a memory latency per scan step for the whole wave;
     // probing FK at a time per lane left most lanes idle (the kernel is VALU-bound once enough frames are in flight).  So
@@ -538,15 +569,34 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
           pos += in ? 1 : 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int p = lane; p < qn; p += 64) {
-          const uint32_t pr = s_q[p];
+        // first part of the segment test for every queued pair; the pairs that can still pass are compacted to the front of
+        // the queue (in place: the write position never passes the read position, and a pass's 64 reads precede its writes)
+        // with their count of right probes in bits 17..18
+        int qm = 0;
+        for (int p0 = 0; p0 < qn; p0 += 64) {
+          const bool in = p0 + lane < qn;
+          const uint32_t pr = in ? s_q[p0 + lane] : 0u;
           const int L = (int)(pr & 63u), c = (int)(pr >> 6);
           const int cL = c0 + wbase + L, iL = s_cidx[cL];                      // lane L of this wave is active: it queued the pair
           const uint32_t pkL = s_pk[cL], e = s_pk[c];
           const int xL = (int)(pkL & 0xFFFFu), yL = (int)(pkL >> 16);
+          int good1 = 0;
+          const bool more = fid_edge_first(g, w, h, xL, yL, (int)(e & 0xFFFFu) - xL, (int)(e >> 16) - yL, -(int)s_dy[iL], (int)s_dx[iL], (int)s_thr[iL], good1) && in;
+          const unsigned long long bal = __ballot(more);
+          __builtin_amdgcn_wave_barrier();
+          if (more) s_q[qm + __popcll(bal & ((1ull << lane) - 1ull))] = pr | ((uint32_t)good1 << 17);
+          qm += __popcll(bal);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int p = lane; p < qm; p += 64) {
+          const uint32_t pr = s_q[p];
+          const int L = (int)(pr & 63u), c = (int)((pr >> 6) & 2047u), good1 = (int)(pr >> 17);
+          const int cL = c0 + wbase + L, iL = s_cidx[cL];
+          const uint32_t pkL = s_pk[cL], e = s_pk[c];
+          const int xL = (int)(pkL & 0xFFFFu), yL = (int)(pkL >> 16);
           const int dxL = s_dx[iL], dyL = s_dy[iL], tL = s_thr[iL];
           const int wx = (int)(e & 0xFFFFu) - xL, wy = (int)(e >> 16) - yL;
-          if (fid_edge_ok(g, w, h, xL, yL, wx, wy, -dyL, dxL, tL))
+          if (fid_edge_rest(g, w, h, xL, yL, wx, wy, -dyL, dxL, tL, good1))
             atomicMin(&s_best[wbase + L], ((unsigned long long)(unsigned)(wx * wx + wy * wy) << 11) | (unsigned long long)c);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -646,8 +696,8 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
 #ifdef RCC_FID_TRACE
   FID_TICK();
   if (tid == 0 && (f & 63) == 0)
-    printf("fid f=%d n=%d nc=%d  class %lld  compact %lld  link %lld  cycles %lld  decode %lld  emit %lld (x10ns)\n", f, n, nc, tk[1] - tk[0], tk[2] - tk[1],
-           tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5]);
+    printf("fid f=%d n=%d nc=%d  class %lld  compact %lld  link: scan %lld nearest-4 probes %lld the rest %lld  cycles %lld  decode %lld  emit %lld (x10ns)\n", f, n, nc,
+           tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3], tk[5] - tk[4], tk[6] - tk[5], tk[7] - tk[6], tk[8] - tk[7]);
 #endif
 }
 

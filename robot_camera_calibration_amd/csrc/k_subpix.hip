@@ -21,7 +21,7 @@
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
                                                rcc_subpix_params sp, const rcc_subpix_lane* __restrict__ tab, int kstride,
-                                               double* __restrict__ pre_xy)
+                                               double* __restrict__ pre_xy, int fid_min_contrast)
 {
   __shared__ double S[SP_MAXP * SP_MAXP];
   const int f = blockIdx.y, q = blockIdx.x;
@@ -44,6 +44,36 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   for (int t = 0; t < GT; ++t) { goff[t] = T.goff[t]; gm[t] = T.gm[t]; gpx[t] = (double)T.gpx[t]; gpy[t] = (double)T.gpy[t]; }
   const rcc_cand c0 = pre[(size_t)f * kstride + q];
   const double x0 = (double)c0.x, y0 = (double)c0.y;
+  if (fid_min_contrast >= 0) {
+    // Square fiducials: only what can become a quad corner is refined.  A candidate whose own pixel fails the convex-black-
+    // corner test of the quad stage (k_fid.hip fid_corner_class: 16 samples on a radius-5 ring against the ring's mid level,
+    // exactly one black arc of 2..7 samples) keeps that pixel as its position: the quad stage's test then fails for it at
+    // the same pixel.  Lane l takes ring sample l & 15; with two transitions the black samples form one arc, so the arc's
+    // length is their count.  About two thirds of a tag scene's candidates (the payload's inner corners) leave here.
+    const int xi = c0.x, yi = c0.y;
+    bool corner = false;
+    if (xi >= 5 && yi >= 5 && xi < w - 5 && yi < h - 5) {          // wave-uniform
+      // ring offsets + 5, one nibble per sample: x = 5 5 4 2 0 -2 -4 -5 -5 -5 -4 -2 0 2 4 5, y = the same a quarter turn on
+      const int k4 = 4 * (lane & 15);
+      const int rx = (int)((0xA9753100013579AAull >> k4) & 15ull) - 5, ry = (int)((0x3100013579AAA975ull >> k4) & 15ull) - 5;
+      const int v = g[(size_t)(yi + ry) * w + (xi + rx)];
+      int lo = v, hi = v;
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+      const int t = (lo + hi) / 2;
+      const unsigned bits = (unsigned)(__builtin_amdgcn_ballot_w64(v > t) & 0xFFFFull);      // bit k: ring sample k is white
+      const unsigned rotl = ((bits << 1) | (bits >> 15)) & 0xFFFFu;
+      const int nblack = 16 - __popc(bits);
+      corner = (hi - lo >= fid_min_contrast) && (__popc(bits ^ rotl) == 2) && nblack >= 2 && nblack <= 7;
+    }
+    if (!corner) {                                                 // wave-uniform
+      if (lane == 0) {
+        pre_xy[((size_t)f * kstride + q) * 2] = x0;
+        pre_xy[((size_t)f * kstride + q) * 2 + 1] = y0;
+      }
+      return;
+    }
+  }
   double cx = x0, cy = y0;
   int iter = 0;
   bool bad = false;
@@ -140,6 +170,7 @@ hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, 
   if (nframes <= 0) return hipSuccess;
   int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
   hipLaunchKernelGGL(k_subpix, dim3(max_kept, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
-                     h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy);
+                     h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy,
+                     c.target_kind == RCC_TARGET_FIDUCIAL ? (c.thr_min_contrast > 0 ? c.thr_min_contrast : 0) : -1);
   return hipGetLastError();
 }

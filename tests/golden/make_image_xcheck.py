@@ -273,6 +273,29 @@ def render_tags(codes, placements, seed=11, noise=1.5, sigma=0.6):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8), np.array(corners)
 
 
+
+def corner_class_np(grey, pts, min_contrast):
+    """The convex-black-corner test of the fiducial stages (DESIGN.md section 3, a4 for fiducials), written from the text with
+    whole-array machinery, for many pixels at once: the 16 pixels nearest to a circle of radius 5 at multiples of 22.5
+    degrees (generated here from the angles, not copied from a table), their mid level, and "the dark samples form one arc
+    of 2 to 7" read off the circular run structure with np.roll / np.diff -- where the oracle walks the ring.  pts: N x 2
+    (x, y); returns N booleans."""
+    g = grey.astype(np.int64)
+    h, w = g.shape
+    ang = np.arange(16) * (np.pi / 8)
+    ring = np.stack([np.rint(5.0 * np.cos(ang)), np.rint(5.0 * np.sin(ang))], 1).astype(np.int64)      # nearest pixel to the circle point
+    pts = np.asarray(pts, np.int64)
+    x, y = pts[:, 0], pts[:, 1]
+    room = (x >= 5) & (y >= 5) & (x < w - 5) & (y < h - 5)
+    xs = np.where(room, x, 5)[:, None] + ring[None, :, 0]
+    ys = np.where(room, y, 5)[:, None] + ring[None, :, 1]
+    v = g[ys, xs]                                                   # (N, 16)
+    lo, hi = v.min(1), v.max(1)
+    white = v > ((lo + hi) // 2)[:, None]
+    changes = (white != np.roll(white, -1, axis=1)).sum(1)
+    dark = (~white).sum(1)
+    return room & (hi - lo >= min_contrast) & (changes == 2) & (dark >= 2) & (dark <= 7)
+
 def refine_edges_np(grey, qi):
     """The refine_edges form of the tag-corner refinement (DESIGN.md section 3, a5 for fiducials), written from the text with
     whole-array machinery: every (edge, sample, offset) position at once by broadcasting, the fixed-point bilinear samples by
@@ -367,6 +390,16 @@ def main():
     out["fid_qi"] = fid_qi
     out["fid_refined"] = np.stack([refine_edges_np(fid_frame, q) for q in fid_qi])
     print("refine_edges (numpy) vs the drawn corners: max |err| per tag", np.abs(out["fid_refined"] - fid_corners[:, ::-1, :]).max(axis=(1, 2)).round(3))
+    # convex-black-corner test: every pixel within 4 px of a drawn tag corner, plus a coarse grid over the frame (payload
+    # corners, edges, flat areas)
+    near = np.rint(fid_corners.reshape(-1, 2)).astype(np.int64)
+    dd = np.stack(np.meshgrid(np.arange(-4, 5), np.arange(-4, 5)), -1).reshape(-1, 2)
+    grid = np.stack(np.meshgrid(np.arange(3, FW, 7), np.arange(2, FH, 5)), -1).reshape(-1, 2)
+    cls_pts = np.concatenate([(near[:, None, :] + dd[None, :, :]).reshape(-1, 2), grid])
+    out["fid_class_pts"] = cls_pts.astype(np.int32)
+    out["fid_class"] = corner_class_np(fid_frame, cls_pts, 32)
+    print("corner class (numpy): %d points, %d convex black corners; at the drawn corners' own pixels: %s" %
+          (len(cls_pts), int(out["fid_class"].sum()), corner_class_np(fid_frame, near, 32).astype(int).tolist()))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "image_xcheck.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; candidates", out["cand_n"], "suppressed", out["pre_n"],
