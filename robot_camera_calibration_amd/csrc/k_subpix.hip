@@ -21,11 +21,12 @@
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
                                                rcc_subpix_params sp, const rcc_subpix_lane* __restrict__ tab, int kstride,
-                                               double* __restrict__ pre_xy, int fid_min_contrast)
+                                               double* __restrict__ pre_xy, int fid_min_contrast, int qstep)
 {
   __shared__ double S[SP_MAXP * SP_MAXP];
-  const int f = blockIdx.y, q = blockIdx.x;
-  if (q >= npre[f]) return;
+  const int f = blockIdx.y;
+  const int np = npre[f];
+  if ((int)blockIdx.x >= np) return;
   const int lane = threadIdx.x;
   const uint8_t* g = grey + (size_t)f * w * h;
   const int win = sp.win;
@@ -42,6 +43,10 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   for (int t = 0; t < PT; ++t) poff[t] = T.poff[t];
 #pragma unroll
   for (int t = 0; t < GT; ++t) { goff[t] = T.goff[t]; gm[t] = T.gm[t]; gpx[t] = (double)T.gpx[t]; gpy[t] = (double)T.gpy[t]; }
+  // candidates blockIdx.x, + qstep, ... of the frame (qstep = the grid's width: one candidate per wave where the lists are
+  // short; tag scenes hold ~750 candidates of up to 2048, two thirds of which leave at the test below, and a wave that finds
+  // its slot unused still costs a slot for a microsecond -- there the grid is narrower than the list and a wave walks it)
+  for (int q = blockIdx.x; q < np; q += qstep) {
   const rcc_cand c0 = pre[(size_t)f * kstride + q];
   const double x0 = (double)c0.x, y0 = (double)c0.y;
   if (fid_min_contrast >= 0) {
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
         pre_xy[((size_t)f * kstride + q) * 2] = x0;
         pre_xy[((size_t)f * kstride + q) * 2 + 1] = y0;
       }
-      return;
+      continue;
     }
   }
   double cx = x0, cy = y0;
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
     pre_xy[((size_t)f * kstride + q) * 2] = cx;
     pre_xy[((size_t)f * kstride + q) * 2 + 1] = cy;
   }
+  }
 }
 
 hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s)
@@ -169,8 +175,22 @@ hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, 
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
   int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
-  hipLaunchKernelGGL(k_subpix, dim3(max_kept, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
+  const bool fid = c.target_kind == RCC_TARGET_FIDUCIAL;
+  // tag scenes: the grid is narrower than the list (measured on 1024 x 1080p with ~750 candidates per frame: width 2048 /
+  // 512 / 256 / 128 / 64 / 32 / 16: 0.63 / 0.55 / 0.49 / 0.46 / 0.44 / 0.48 / 0.52 ms) -- at least 64 wide, and wide
+  // enough that a small batch still puts four waves on every slot of the device
+  int qstep = max_kept;
+  if (fid) {
+    qstep = (24576 + nframes - 1) / nframes;
+    if (qstep < 64) qstep = 64;
+#ifdef RCC_EXPERIMENTS
+    static const int qs_env = getenv("RCC_SUBPIX_QSTEP") ? atoi(getenv("RCC_SUBPIX_QSTEP")) : 0;
+    if (qs_env > 0) qstep = qs_env;
+#endif
+    if (qstep > max_kept) qstep = max_kept;
+  }
+  hipLaunchKernelGGL(k_subpix, dim3(qstep, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
                      h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy,
-                     c.target_kind == RCC_TARGET_FIDUCIAL ? (c.thr_min_contrast > 0 ? c.thr_min_contrast : 0) : -1);
+                     fid ? (c.thr_min_contrast > 0 ? c.thr_min_contrast : 0) : -1, qstep);
   return hipGetLastError();
 }
