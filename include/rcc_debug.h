@@ -47,6 +47,9 @@ int rcc_set_pipeline(rcc_handle* h, int nchunks);
  * frames per chunk (0 = automatic, about 192 MiB; < 0 = one copy of the whole batch, then the kernels -- the A/B form).
  * Same records either way.  Returns the previous setting. */
 int rcc_set_host_chunk(rcc_handle* h, int frames_per_chunk);
+/* tag scenes: width of k_subpix's grid -- a wave walks its frame's candidate list with this stride (0 = automatic: at least 64,
+ * wider for small batches; k_subpix.hip).  Same refined positions at any width.  Returns the previous setting. */
+int rcc_set_subpix_grid(rcc_handle* h, int width);
 /* PnP mapping: 0 = one lane per target, 1 = one wavefront per target with more than 8 points, -1 = automatic (= 1) */
 int rcc_set_pnp_variant(rcc_handle* h, int variant);
 
@@ -87,15 +90,15 @@ int rcc_debug_pnp_probe(rcc_handle* h, const double* obj, const double* img, int
  * back on one stream (mode 0) or launched together on two streams (mode 1); mean milliseconds per pair. */
 int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,
                       void* d_cand, void* d_cand_count, int32_t mode, int32_t reps, float* mean_ms);
+/* experiment: the wave-per-window threshold + corner pass reads the grey rows of frame (f mod m) -- a working set small enough
+ * to stay in the Infinity Cache; m = 0: off.  Results are then those of the wrong frames. */
+int rcc_set_dense_fmod(rcc_handle* h, int32_t m);
 /* experiment (scratch/t_grid_trace.py): per-frame phase time stamps of k_grid_pnp -- d_buf: nframes x 24 int64 (device), slots
  * 0 start, 1 seeds done, 3 growth starts, 2 growth done, 5 lattice done, 6 pose done (10-ns ticks), 7 = seed attempt * 1000 + labels,
  * 8 homography starts, 9 DLT done, 10 refinement done, 11 homography returned, 12 initial pose done, 13 = refinement iterations,
  * 16..23 = time spent in: H accumulate (full), H accumulate (trial), H 8x8 solve, H rest, pose accumulate (full), pose accumulate (trial),
  * pose 6x6 solve, (unused);
  * NULL switches it off. */
-/* experiment: the wave-per-window threshold + corner pass reads the grey rows of frame (f mod m) -- a working set small enough
- * to stay in the Infinity Cache; m = 0: off.  Results are then those of the wrong frames. */
-int rcc_set_dense_fmod(rcc_handle* h, int32_t m);
 int rcc_debug_grid_trace(rcc_handle* h, void* d_buf);
 #endif
 

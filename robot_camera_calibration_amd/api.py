@@ -93,6 +93,8 @@ def load_library():
     L.rcc_set_dense_gang.restype = C.c_int
     L.rcc_set_host_chunk.argtypes = [P, C.c_int]
     L.rcc_set_host_chunk.restype = C.c_int
+    L.rcc_set_subpix_grid.argtypes = [P, C.c_int]
+    L.rcc_set_subpix_grid.restype = C.c_int
     L.rcc_set_pipeline.argtypes = [P, C.c_int]
     L.rcc_set_pipeline.restype = C.c_int
     L.rcc_set_pnp_variant.restype = C.c_int
@@ -133,7 +135,7 @@ EXPORTED_SYMBOLS = (
 )
 # include/rcc_debug.h: test taps, timers, A/B switches between bit-identical variants (not part of the boundary)
 DEBUG_EXPORTED_SYMBOLS = (
-    "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_set_dense_skip", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline", "rcc_set_host_chunk", "rcc_set_dense_gang",
+    "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_set_dense_skip", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline", "rcc_set_host_chunk", "rcc_set_dense_gang", "rcc_set_subpix_grid",
     "rcc_set_pnp_variant", "rcc_last_timings", "rcc_last_dense_kernel", "rcc_time_dense", "rcc_time_ingest", "rcc_time_copy",
     "rcc_debug_calib_copy", "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_debug_pnp_probe",
 )
@@ -384,6 +386,10 @@ class Detector:
     def set_host_chunk(self, frames_per_chunk):
         """host-resident input: frames per chunk of the copy / compute pipeline (0 automatic, < 0 one copy then the kernels)"""
         return self._L.rcc_set_host_chunk(self._h, int(frames_per_chunk))
+
+    def set_subpix_grid(self, width):
+        """tag scenes: width of the sub-pixel kernel's grid (waves walk the candidate list with this stride; 0 automatic)"""
+        return self._L.rcc_set_subpix_grid(self._h, int(width))
 
     def set_pnp_mfma(self, on):
         """1: 4-point tag poses accumulate their normal equations on the matrix cores (cfg.pnp_use_mfma); returns the previous setting"""

@@ -183,10 +183,7 @@ hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, 
   if (fid) {
     qstep = (24576 + nframes - 1) / nframes;
     if (qstep < 64) qstep = 64;
-#ifdef RCC_EXPERIMENTS
-    static const int qs_env = getenv("RCC_SUBPIX_QSTEP") ? atoi(getenv("RCC_SUBPIX_QSTEP")) : 0;
-    if (qs_env > 0) qstep = qs_env;
-#endif
+    if (h->subpix_grid > 0) qstep = h->subpix_grid;       // rcc_set_subpix_grid
     if (qstep > max_kept) qstep = max_kept;
   }
   hipLaunchKernelGGL(k_subpix, dim3(qstep, nframes), dim3(64), 0, s, d_grey, c.width, c.height,

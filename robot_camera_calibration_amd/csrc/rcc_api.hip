@@ -756,6 +756,13 @@ int rcc_set_keep_binary(rcc_handle* h, int on)
 
 // host-resident batches: frames per chunk of the copy / compute pipeline (0 automatic, < 0 one copy then the kernels);
 // returns the previous setting
+int rcc_set_subpix_grid(rcc_handle* h, int width)
+{
+  if (!h || width < 0) return RCC_ERR_ARG;
+  int p = h->subpix_grid;
+  h->subpix_grid = width;
+  return p;
+}
 int rcc_set_host_chunk(rcc_handle* h, int frames_per_chunk)
 {
   if (!h) return RCC_ERR_ARG;

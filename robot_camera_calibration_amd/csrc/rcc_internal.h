@@ -123,6 +123,7 @@ struct rcc_handle {
   uint64_t* d_family;       // fiducial family table (device copy)
   int pnp_wave_hint;        // set per rcc_solve_pnp_batch call: max points per target > 8
   rcc_subpix_params sp;
+  int subpix_grid;           // rcc_set_subpix_grid: width of k_subpix's grid in tag scenes; 0 = automatic
   rcc_subpix_lane* d_sp_tab;   // 64 entries
   char err[256];
 };

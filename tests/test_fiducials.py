@@ -121,6 +121,36 @@ def test_hip_fiducials_match_oracle(oracle, refine):
     det.close()
 
 
+
+@pytest.mark.gpu
+def test_hip_subpix_grid_width_does_not_change_results():
+    """tag scenes: the sub-pixel kernel's grid is narrower than the candidate list and a wave walks the list (the automatic width
+    only gets below the list's length on batches of hundreds of frames: rcc_set_subpix_grid forces it here).  Widths 1, 7, 64 and
+    the full list give the same refined positions and the same detections, bit for bit -- also for the candidates that leave at
+    the convex-black-corner test and keep their pixel."""
+    import torch
+    cfg, fam = _cfg(api.default_config, B=3)
+    (hx, hy), centres, ids, sp = _scene(cfg)
+    det = api.Detector(cfg)
+    n = 3
+    poses = np.concatenate([synth.sample_poses(1, cfg, seed=200 + f, z_range=(0.9, 1.6), max_tilt_deg=40, half_extent_m=(hx, hy)) for f in range(n)])
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    ref = None
+    for width in (0, 1, 7, 64, 100000):
+        det.set_subpix_grid(width)
+        dets, fcs = det.detect(frames, n)
+        lst = det.fetch_lists(n)
+        assert (lst["npre"] > 300).all()                                    # far more candidates than the narrow grids are wide
+        got = (dets.tobytes(), b"".join(lst["pre_xy"][f][:lst["npre"][f]].tobytes() for f in range(n)), lst["npre"].tobytes())
+        if ref is None:
+            ref = got
+            assert len(dets) == n * GX * GY
+            kept_pixel = sum(int((lst["pre_xy"][f][:lst["npre"][f]] == np.stack([lst["pre"][f]["x"], lst["pre"][f]["y"]], 1)[:lst["npre"][f]]).all(axis=1).sum()) for f in range(n))
+            assert kept_pixel > int(lst["npre"].sum()) // 3                 # the corner test in front of the refinement sends many home
+        assert got == ref, "grid width %d" % width
+    det.close()
+
 def _clutter(img, w, h, seed, count):
     """paste black / white / grey rectangles over a BGR frame (destroys some tags: only equality with the oracle is asked)"""
     rng = np.random.default_rng(seed)
