@@ -21,12 +21,17 @@ __global__ __launch_bounds__(256) void k_list_sort_nms(const rcc_cand* __restric
                                                        rcc_cand* __restrict__ pre, int32_t* __restrict__ npre,
                                                        rcc_frame_corners* __restrict__ fc)
 {
-  __shared__ rcc_cand raw[LIST_MAX];
-  __shared__ rcc_cand srt[LIST_MAX];
-  __shared__ int s_cnt[256];
-  __shared__ int s_off[257];
-  __shared__ __attribute__((aligned(16))) unsigned short s_start[BUCKETS ? LIST_MAXH + 2 : 2];   // first sorted index of each row (after the scan)
-  __shared__ __attribute__((aligned(16))) unsigned short s_fill[BUCKETS ? LIST_MAXH + 2 : 2];    // per-row counters
+  // LDS sized by the launch for this configuration's list capacity and image height (list_lds_bytes): two lists of `cap`
+  // entries and, for the bucket path, two 16-bit tables of height + 2 rows.  (Sized for the largest configuration --
+  // 4096 entries, 4096 rows: 84 KB -- a CU held one workgroup; the board's 2048 x 1080 needs 37 KB: four.)
+  extern __shared__ __attribute__((aligned(16))) uint8_t list_lds[];
+  const int rows_al = BUCKETS ? ((height + 2 + 7) & ~7) : 8;
+  rcc_cand* const raw = reinterpret_cast<rcc_cand*>(list_lds);
+  rcc_cand* const srt = raw + cap;
+  unsigned short* const s_start = reinterpret_cast<unsigned short*>(srt + cap);   // first sorted index of each row (after the scan)
+  unsigned short* const s_fill = s_start + rows_al;                               // per-row counters
+  int* const s_cnt = reinterpret_cast<int*>(s_fill + rows_al);                     // 256
+  int* const s_off = s_cnt + 256;                                                  // 257
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   const int count = cand_count[f];
@@ -157,11 +162,20 @@ hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t*
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
   int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
-  if (c.height <= LIST_MAXH - 1)
-    hipLaunchKernelGGL(k_list_sort_nms<1>, dim3(nframes), dim3(256), 0, s, d_cand, d_cand_count,
+  const bool buckets = c.height <= LIST_MAXH - 1;
+  const size_t lds = 2 * (size_t)c.max_candidates * sizeof(rcc_cand) + 2 * (size_t)(buckets ? ((c.height + 2 + 7) & ~7) : 8) * sizeof(unsigned short) +
+                     (256 + 257) * sizeof(int);
+  if (lds > 64 * 1024) {
+    // beyond the default limit of dynamic LDS: raise it for the instantiation about to be launched (idempotent)
+    hipError_t ea = buckets ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_list_sort_nms<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                            : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_list_sort_nms<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ea != hipSuccess) return ea;
+  }
+  if (buckets)
+    hipLaunchKernelGGL(k_list_sort_nms<1>, dim3(nframes), dim3(256), lds, s, d_cand, d_cand_count,
                        c.max_candidates, c.height, c.nms_radius, max_kept, h->kept_cap, h->d_pre, h->d_npre, h->d_fc);
   else
-    hipLaunchKernelGGL(k_list_sort_nms<0>, dim3(nframes), dim3(256), 0, s, d_cand, d_cand_count,
+    hipLaunchKernelGGL(k_list_sort_nms<0>, dim3(nframes), dim3(256), lds, s, d_cand, d_cand_count,
                        c.max_candidates, c.height, c.nms_radius, max_kept, h->kept_cap, h->d_pre, h->d_npre, h->d_fc);
   return hipGetLastError();
 }
