@@ -18,6 +18,7 @@
 // grid (max_kept, nframes): the wave handles candidate blockIdx.x of frame blockIdx.y.  (Several corners per wave, to
 // share the table setup, measured slower once the tables came from rcc_create: the longer chain per wave costs more in
 // the launch's tail than the ~15 saved loads.)
+template <bool FID>       // FID: tag scenes (the convex-black-corner test in front of the refinement, waves walk the candidate list)
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
                                                rcc_subpix_params sp, const rcc_subpix_lane* __restrict__ tab, int kstride,
@@ -46,38 +47,56 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   // candidates blockIdx.x, + qstep, ... of the frame (qstep = the grid's width: one candidate per wave where the lists are
   // short; tag scenes hold ~750 candidates of up to 2048, two thirds of which leave at the test below, and a wave that finds
   // its slot unused still costs a slot for a microsecond -- there the grid is narrower than the list and a wave walks it)
-  for (int q = blockIdx.x; q < np; q += qstep) {
-  const rcc_cand c0 = pre[(size_t)f * kstride + q];
-  const double x0 = (double)c0.x, y0 = (double)c0.y;
-  if (fid_min_contrast >= 0) {
+  constexpr bool fid = FID;
+  const int per_pass = fid ? 4 : 1;
+  for (int q0 = blockIdx.x; q0 < np; q0 += per_pass * qstep) {
+  unsigned refine_m = 1u;                  // bit k: candidate q0 + k * qstep is refined
+  int cgx = 0, cgy = 0;                    // fid: the candidate of this lane's group of 16
+  if (fid) {
     // Square fiducials: only what can become a quad corner is refined.  A candidate whose own pixel fails the convex-black-
     // corner test of the quad stage (k_fid.hip fid_corner_class: 16 samples on a radius-5 ring against the ring's mid level,
     // exactly one black arc of 2..7 samples) keeps that pixel as its position: the quad stage's test then fails for it at
-    // the same pixel.  Lane l takes ring sample l & 15; with two transitions the black samples form one arc, so the arc's
-    // length is their count.  About two thirds of a tag scene's candidates (the payload's inner corners) leave here.
-    const int xi = c0.x, yi = c0.y;
-    bool corner = false;
-    if (xi >= 5 && yi >= 5 && xi < w - 5 && yi < h - 5) {          // wave-uniform
-      // ring offsets + 5, one nibble per sample: x = 5 5 4 2 0 -2 -4 -5 -5 -5 -4 -2 0 2 4 5, y = the same a quarter turn on
-      const int k4 = 4 * (lane & 15);
-      const int rx = (int)((0xA9753100013579AAull >> k4) & 15ull) - 5, ry = (int)((0x3100013579AAA975ull >> k4) & 15ull) - 5;
-      const int v = g[(size_t)(yi + ry) * w + (xi + rx)];
-      int lo = v, hi = v;
+    // the same pixel.  About two thirds of a tag scene's candidates (the payload's inner corners) leave here, so the test is
+    // made for FOUR candidates per pass -- the four 16-lane groups of the wave, lane l of a group on ring sample l -- and its
+    // two dependent reads (candidate, ring pixel) are paid once for the four; with two transitions the black samples form
+    // one arc, so the arc's length is their count.
+    const int grp = lane >> 4;
+    const int myq = q0 + grp * qstep;
+    const bool valid = myq < np;
+    rcc_cand cg; cg.x = 0; cg.y = 0; cg.score = 0;
+    if (valid) cg = pre[(size_t)f * kstride + myq];
+    const int xi = cg.x, yi = cg.y;
+    cgx = xi; cgy = yi;
+    const bool room = valid && xi >= 5 && yi >= 5 && xi < w - 5 && yi < h - 5;        // uniform over the group
+    // ring offsets + 5, one nibble per sample: x = 5 5 4 2 0 -2 -4 -5 -5 -5 -4 -2 0 2 4 5, y = the same a quarter turn on
+    const int k4 = 4 * (lane & 15);
+    const int rx = (int)((0xA9753100013579AAull >> k4) & 15ull) - 5, ry = (int)((0x3100013579AAA975ull >> k4) & 15ull) - 5;
+    const int v = room ? (int)g[(size_t)(yi + ry) * w + (xi + rx)] : 0;
+    int lo = v, hi = v;
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
-      const int t = (lo + hi) / 2;
-      const unsigned bits = (unsigned)(__builtin_amdgcn_ballot_w64(v > t) & 0xFFFFull);      // bit k: ring sample k is white
-      const unsigned rotl = ((bits << 1) | (bits >> 15)) & 0xFFFFu;
-      const int nblack = 16 - __popc(bits);
-      corner = (hi - lo >= fid_min_contrast) && (__popc(bits ^ rotl) == 2) && nblack >= 2 && nblack <= 7;
+    for (int off = 1; off < 16; off <<= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+    const int t = (lo + hi) / 2;
+    const unsigned long long wb = __builtin_amdgcn_ballot_w64(v > t);
+    const unsigned bits = (unsigned)(wb >> (16 * grp)) & 0xFFFFu;                       // bit k: ring sample k of this group's candidate is white
+    const unsigned rotl = ((bits << 1) | (bits >> 15)) & 0xFFFFu;
+    const int nblack = 16 - __popc(bits);
+    const bool corner = room && (hi - lo >= fid_min_contrast) && (__popc(bits ^ rotl) == 2) && nblack >= 2 && nblack <= 7;
+    if (valid && !corner && (lane & 15) == 0) {
+      pre_xy[((size_t)f * kstride + myq) * 2] = (double)xi;
+      pre_xy[((size_t)f * kstride + myq) * 2 + 1] = (double)yi;
     }
-    if (!corner) {                                                 // wave-uniform
-      if (lane == 0) {
-        pre_xy[((size_t)f * kstride + q) * 2] = x0;
-        pre_xy[((size_t)f * kstride + q) * 2 + 1] = y0;
-      }
-      continue;
-    }
+    const unsigned long long cb = __builtin_amdgcn_ballot_w64(corner);
+    refine_m = (unsigned)(cb & 1ull) | ((unsigned)((cb >> 16) & 1ull) << 1) | ((unsigned)((cb >> 32) & 1ull) << 2) | ((unsigned)((cb >> 48) & 1ull) << 3);
+  }
+  for (int kq = 0; kq < per_pass; ++kq) {
+  if (!((refine_m >> kq) & 1u)) continue;                           // wave-uniform
+  const int q = q0 + kq * qstep;
+  double x0, y0;
+  if (fid) {
+    x0 = (double)__shfl(cgx, 16 * kq, 64); y0 = (double)__shfl(cgy, 16 * kq, 64);
+  } else {
+    const rcc_cand c0 = pre[(size_t)f * kstride + q];
+    x0 = (double)c0.x; y0 = (double)c0.y;
   }
   double cx = x0, cy = y0;
   int iter = 0;
@@ -168,6 +187,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
     pre_xy[((size_t)f * kstride + q) * 2 + 1] = cy;
   }
   }
+  }
 }
 
 hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, hipStream_t s)
@@ -186,8 +206,11 @@ hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, 
     if (h->subpix_grid > 0) qstep = h->subpix_grid;       // rcc_set_subpix_grid
     if (qstep > max_kept) qstep = max_kept;
   }
-  hipLaunchKernelGGL(k_subpix, dim3(qstep, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
-                     h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy,
-                     fid ? (c.thr_min_contrast > 0 ? c.thr_min_contrast : 0) : -1, qstep);
+  if (fid)
+    hipLaunchKernelGGL(k_subpix<true>, dim3(qstep, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
+                       h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy, c.thr_min_contrast > 0 ? c.thr_min_contrast : 0, qstep);
+  else
+    hipLaunchKernelGGL(k_subpix<false>, dim3(qstep, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
+                       h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy, -1, qstep);
   return hipGetLastError();
 }
