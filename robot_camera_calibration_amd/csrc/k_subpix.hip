@@ -15,9 +15,11 @@
 #define SP_MAXW 7
 #define SP_MAXP (2 * SP_MAXW + 3)
 
-// grid (max_kept, nframes): the wave handles candidate blockIdx.x of frame blockIdx.y.  (Several corners per wave, to
-// share the table setup, measured slower once the tables came from rcc_create: the longer chain per wave costs more in
-// the launch's tail than the ~15 saved loads.)
+// Board scenes (FID = false): grid (max_kept, nframes), the wave handles candidate blockIdx.x of frame blockIdx.y.  (Several
+// corners per wave, to share the table setup, measured slower there once the tables came from rcc_create: the longer chain
+// per wave costs more in the launch's tail than the ~15 saved loads.)  Tag scenes (FID = true): grid (qstep, nframes) with
+// qstep well below the list's length; a wave walks its frame's list four candidates at a time -- see below and
+// rcc_launch_subpix.
 template <bool FID>       // FID: tag scenes (the convex-black-corner test in front of the refinement, waves walk the candidate list)
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
