@@ -492,7 +492,9 @@ int rcc_stage_targets(rcc_handle* h, const void* d_grey, const void* d_bin, cons
 static int ensure_stage(rcc_handle* h, size_t need, bool may_realloc)
 {
   if (need <= h->stage_bytes) return RCC_OK;
-  if (!may_realloc) return RCC_ERR_STATE;          // cannot re-allocate the staging buffer under a batch in flight
+  // a staging buffer that exists cannot be replaced under a batch in flight (it cannot be too small either: it is allocated
+  // for the handle's capacity); one that does not exist yet -- the batch in flight came from device memory -- is simply made
+  if (!may_realloc && h->d_stage) return RCC_ERR_STATE;
   if (h->d_stage) (void)hipFree(h->d_stage);
   h->d_stage = nullptr;
   h->stage_bytes = 0;

@@ -603,6 +603,12 @@ def test_host_input_pipeline_identical(torch_cuda):
         outs.append(det.collect()); outs.append(det.collect())
     det.set_host_chunk(0)
     outs.append(det.detect(host.numpy(), n))                 # pageable numpy memory takes the same path
+    # a host-resident batch submitted while a device-resident one is in flight, on a handle that has not staged anything yet
+    det2 = api.Detector(cfg)
+    det2.submit(frames, n, want_corners=True)
+    det2.submit(host, n, want_corners=True)
+    outs.append(det2.collect()); outs.append(det2.collect())
+    det2.close()
     assert len(d_dev) >= n - 3 and 17 not in set(d_dev.frame.tolist())
     assert d_one.tobytes() == d_dev.tobytes() and f_one.tobytes() == f_dev.tobytes()
     for d, f in outs:
