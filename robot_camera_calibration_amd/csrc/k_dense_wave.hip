@@ -54,6 +54,15 @@ void rcc_dense_wave_plan(const rcc_handle* h, int nframes, rcc_wave_plan* p)
   const int th = c.height >> 2;
   int nseg = (th + 17) / 34;
   if (nseg < 1) nseg = 1;
+  // a batch too small to fill the device (one frame per call is what the ROS node does): shorter segments, down to 8 tile
+  // rows, until the jobs fill the wave slots -- the jobs are dependent chains, and with slots to spare the chain's length is
+  // the pass's duration (one 1080p frame: 51 us at 8 segments of 34 tile rows)
+  {
+    static const int cus = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
+    const long long slots = 24LL * cus;
+    const int nseg_max = th / 8 > 1 ? th / 8 : 1;
+    while (nseg < nseg_max && (long long)p->nbands * p->nwin * nseg * nframes < slots) ++nseg;
+  }
   p->seg_tiles = (th + nseg - 1) / nseg;
   p->nseg = (th + p->seg_tiles - 1) / p->seg_tiles;
   p->njobs = (long long)p->nbands * p->nseg * p->nwin * ((nframes + 8 * p->fchunk - 1) / (8 * p->fchunk)) * 8 * p->fchunk;

@@ -36,6 +36,11 @@ __global__ __launch_bounds__(256) void k_list_sort_nms(const rcc_cand* __restric
   const int tid = threadIdx.x;
   const int count = cand_count[f];
   rcc_frame_corners* out = fc + f;
+  // the frame's table starts from zero (a frame without a target then reads the same on every handle and in every call: the
+  // later kernels write the counts and, for a found board, its corners -- nothing behind ncorners)
+  static_assert(sizeof(rcc_frame_corners) % 4 == 0, "frame table in dwords");
+  for (int i = tid; i < (int)(sizeof(rcc_frame_corners) / 4); i += 256) reinterpret_cast<uint32_t*>(out)[i] = 0u;
+  __syncthreads();
   if (tid == 0) {
     out->status = 0;
     out->ncand = count;

@@ -408,9 +408,6 @@ static int launch_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d
 {
   const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
   if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
-  // the frame tables start from zero: a frame without a target then reads the same on every handle and in every call (the
-  // kernels write the counts and, for a found board, its corners -- what lies behind ncorners was whatever the memory held)
-  HIPCHK(h, hipMemsetAsync(h->d_fc, 0, sizeof(rcc_frame_corners) * (size_t)nframes, s));
   HIPCHK(h, rcc_launch_list(h, d_cand, d_cand_count, nframes, s));
   HIPCHK(h, rcc_launch_subpix(h, d_grey, nframes, s));
   const bool fused = !fid && h->fuse_grid_pnp && rcc_grid_pnp_applicable(h);   // lattice indexing + pose in one launch
