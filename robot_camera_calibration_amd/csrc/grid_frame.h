@@ -96,20 +96,27 @@ __device__ __forceinline__ bool ring_ok(const BinSrc& b, int w, int h, int x, in
 // ---- wave-uniform helpers: values that are the same in every lane live in scalar registers ------------------------------
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // lane l (uniform) of register jj (uniform, 0..3) of a 4-register array: point / queue entry lane + 64 * jj
-__device__ __forceinline__ int pick4(const int (&r)[4], int idx)
+// J registers per lane hold 64 J values: J = 4 covers the list's 256 entries, J = 1 the common case of at most 64 validated
+// points (a board frame keeps ~50), where every select below disappears
+template <int J>
+__device__ __forceinline__ int pick4(const int (&r)[J], int idx)
 {
-  const int jj = idx >> 6, l = idx & 63;
-  return jj == 0 ? __builtin_amdgcn_readlane(r[0], l) : jj == 1 ? __builtin_amdgcn_readlane(r[1], l)
-       : jj == 2 ? __builtin_amdgcn_readlane(r[2], l) : __builtin_amdgcn_readlane(r[3], l);
-}
-__device__ __forceinline__ void put4(int (&r)[4], int idx, int val, int lane)
-{
+  const int l = idx & 63;
+  if (J == 1) return __builtin_amdgcn_readlane(r[0], l);
   const int jj = idx >> 6;
+  return jj == 0 ? __builtin_amdgcn_readlane(r[0], l) : jj == 1 ? __builtin_amdgcn_readlane(r[1 % J], l)
+       : jj == 2 ? __builtin_amdgcn_readlane(r[2 % J], l) : __builtin_amdgcn_readlane(r[3 % J], l);
+}
+template <int J>
+__device__ __forceinline__ void put4(int (&r)[J], int idx, int val, int lane)
+{
   const bool mine = lane == (idx & 63);
+  if (J == 1) { r[0] = mine ? val : r[0]; return; }
+  const int jj = idx >> 6;
   if (jj == 0) r[0] = mine ? val : r[0];
-  else if (jj == 1) r[1] = mine ? val : r[1];
-  else if (jj == 2) r[2] = mine ? val : r[2];
-  else r[3] = mine ? val : r[3];
+  else if (jj == 1) r[1 % J] = mine ? val : r[1 % J];
+  else if (jj == 2) r[2 % J] = mine ? val : r[2 % J];
+  else r[3 % J] = mine ? val : r[3 % J];
 }
 
 // The frame's validated points live in REGISTERS during the lattice growth: lane l holds points l, l + 64, l + 128,
@@ -122,14 +129,14 @@ __device__ __forceinline__ void put4(int (&r)[4], int idx, int val, int lane)
 // dword and the wave-wide minimum a 32-bit reduction.  A query outside the image may be farther than 2^24 - 2 from every
 // point; its distance saturates there, and such a match is refused by the caller either way (8 * distance > step^2,
 // step^2 < 2^24).
-template <bool SMALL>
-__device__ __forceinline__ int nearest_free(const int (&pxr)[4], const int (&pyr)[4], const unsigned usedm, const int nk, const int lane,
+template <bool SMALL, int J>
+__device__ __forceinline__ int nearest_free(const int (&pxr)[J], const int (&pyr)[J], const unsigned usedm, const int nk, const int lane,
                                             const int qx, const int qy, long long* dist)
 {
   if (SMALL) {
     unsigned best = ~0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < J; ++j) {
       if (64 * j >= nk) break;                       // uniform
       const int k = lane + 64 * j;
       const int dx = pxr[j] - qx, dy = pyr[j] - qy;
@@ -146,7 +153,7 @@ __device__ __forceinline__ int nearest_free(const int (&pxr)[4], const int (&pyr
   }
   unsigned long long best = ~0ull;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < J; ++j) {
     if (64 * j >= nk) break;
     const int k = lane + 64 * j;
     const long long dx = (long long)pxr[j] - qx, dy = (long long)pyr[j] - qy;
@@ -255,6 +262,209 @@ struct grid_smem {
   int16_t tmp[RCC_MAX_KEPT], t2[RCC_MAX_KEPT];
   int32_t order[RCC_MAX_KEPT];
 };
+// the lattice of a board frame from its validated points (list order in sm.px / sm.py): J = 1 for at most 64 points, else 4
+template <int J>
+__device__ __forceinline__ bool lattice_board(grid_smem& sm, const int f, const int lane, const int nk, const int cols, const int rows, const int need, const bool small)
+{
+  bool found_board = false;
+  int pxr[J], pyr[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int k = lane + 64 * j;
+    pxr[j] = (k < nk) ? sm.px[k] : 0;
+    pyr[j] = (k < nk) ? sm.py[k] : 0;
+  }
+  long long sx = 0, sy = 0;
+#pragma unroll
+  for (int j = 0; j < J; ++j) if (lane + 64 * j < nk) { sx += pxr[j]; sy += pyr[j]; }
+  sx = wave_sum_i64(sx);
+  sy = wave_sum_i64(sy);
+  // seeds: the 8 points nearest the centroid, nearest first; seed s is kept in lane s of seedreg
+  unsigned takenm = 0;
+  int seedreg = 0;
+  const int nseeds = nk < 8 ? nk : 8;
+  for (int s = 0; s < nseeds; ++s) {
+    unsigned long long best = ~0ull;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int i = lane + 64 * j;
+      if (i < nk && !((takenm >> j) & 1u)) {
+        const long long ex = (long long)nk * pxr[j] - sx, ey = (long long)nk * pyr[j] - sy;
+        const unsigned long long key = ((unsigned long long)(ex * ex + ey * ey) << 8) | (unsigned long long)i;
+        best = key < best ? key : best;
+      }
+    }
+    best = wave_min_u64(best);
+    const int bi = uni((int)(best & 255ull));
+    if (lane == (bi & 63)) takenm |= 1u << (bi >> 6);
+    if (lane == s) seedreg = bi;
+  }
+  GTRACE(1);
+  // packed cell offsets of the 3 x 3 neighbourhood a lane < 9 reads: cell (i + lane / 3 - 1, j + lane % 3 - 1)
+  const int nb_off = (lane < 9) ? ((lane / 3 - 1) * GW + (lane % 3 - 1)) : 0;
+
+  for (int si = 0; si < nseeds && !found_board; ++si) {
+    const int s = uni(__builtin_amdgcn_readlane(seedreg, si));
+    __syncthreads();
+    for (int i = lane; i < GW * GW; i += 64) sm.labp[i] = -1;
+    unsigned usedm = (lane == (s & 63)) ? (1u << (s >> 6)) : 0u;
+    int cellr[J] = {};                // lattice cell (i + GM) | (j + GM) << 8 of the lane's points, where their used bit is set
+    int qreg[J] = {};                  // the growth queue: entry e (a cell, packed as above) in lane e & 63 of register e >> 6
+    // give point k the cell (ti, tj): flags, the cell of the point, the label table (packed coordinates of the point)
+    auto claim = [&](const int k, const int ti, const int tj, const int packed_xy) {
+      const int cellp = (ti + GM) | ((tj + GM) << 8);
+      const bool mine = lane == (k & 63);
+      const int kj = k >> 6;
+      usedm |= mine ? (1u << kj) : 0u;
+#pragma unroll
+      for (int j = 0; j < J; ++j) cellr[j] = (mine && j == kj) ? cellp : cellr[j];
+      if (lane == 0) LABP(ti, tj) = packed_xy;
+      return cellp;
+    };
+    const int sxp = pick4<J>(pxr, s), syp = pick4<J>(pyr, s);
+    long long dd;
+    const int n1 = small ? nearest_free<true, J>(pxr, pyr, usedm, nk, lane, sxp, syp, &dd) : nearest_free<false, J>(pxr, pyr, usedm, nk, lane, sxp, syp, &dd);
+    if (n1 < 0) continue;
+    const int n1x = pick4<J>(pxr, n1), n1y = pick4<J>(pyr, n1);
+    const long long ux = n1x - sxp, uy = n1y - syp;
+    const long long uu = ux * ux + uy * uy;
+    unsigned long long best = ~0ull;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int k = lane + 64 * j;
+      if (k >= nk || k == s || k == n1) continue;
+      const long long wx = pxr[j] - sxp, wy = pyr[j] - syp;
+      const long long cr = ux * wy - uy * wx;
+      const long long wwv = wx * wx + wy * wy;
+      if (4 * cr * cr < uu * wwv) continue;
+      const unsigned long long key = ((unsigned long long)wwv << 8) | (unsigned long long)k;
+      best = key < best ? key : best;
+    }
+    best = wave_min_u64(best);
+    const unsigned blo = (unsigned)uni((int)(unsigned)best), bhi = (unsigned)uni((int)(unsigned)(best >> 32));
+    if (blo == ~0u && bhi == ~0u) continue;
+    const int n2 = (int)(blo & 255u);
+    const int n2x = pick4<J>(pxr, n2), n2y = pick4<J>(pyr, n2);
+    const long long vx = n2x - sxp, vy = n2y - syp;
+
+    put4<J>(qreg, 0, claim(s, 0, 0, sxp | (syp << 16)), lane);
+    put4<J>(qreg, 1, claim(n1, 1, 0, n1x | (n1y << 16)), lane);
+    put4<J>(qreg, 2, claim(n2, 0, 1, n2x | (n2y << 16)), lane);
+    int qh = 0, qt = 3, L = 3;
+    __syncthreads();                 // the cleared table and the three labels are in place
+    GTRACE(3);
+    while (qh < qt) {
+      const int cell = pick4<J>(qreg, qh);
+      ++qh;
+      const int i = (cell & 255) - GM, j = (cell >> 8) - GM;
+      // the 3 x 3 neighbourhood of (i, j) in ONE LDS round trip: lane c < 9 holds the packed coordinates of the point at
+      // cell (i + c / 3 - 1, j + c % 3 - 1), or -1.  Every rule below reads only these nine cells; a label set for
+      // direction d is patched into the register copy, so the later directions see it as the serial definition does.
+      int nbv = -1;
+      if (lane < 9) nbv = sm.labp[(i + GM) * GW + (j + GM) + nb_off];
+      const int a = __builtin_amdgcn_readlane(nbv, 4);
+      const int ax = a & 0xFFFF, ay = a >> 16;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int di = (d == 0) ? 1 : (d == 1) ? -1 : 0;
+        const int dj = (d == 2) ? 1 : (d == 3) ? -1 : 0;
+        const int ti = i + di, tj = j + dj;
+        if (ti < -GM + 1 || ti > GM - 1 || tj < -GM + 1 || tj > GM - 1) continue;
+        const int tc = (1 + di) * 3 + (1 + dj);
+        if (__builtin_amdgcn_readlane(nbv, tc) >= 0) continue;
+        int predx = 0, predy = 0;
+        long long step2 = 0;
+        bool have = false;
+        const int opp = __builtin_amdgcn_readlane(nbv, (1 - di) * 3 + (1 - dj));
+        if (opp >= 0) {
+          const int bx = opp & 0xFFFF, by = opp >> 16;
+          predx = 2 * ax - bx; predy = 2 * ay - by;
+          step2 = (long long)(ax - bx) * (ax - bx) + (long long)(ay - by) * (ay - by);
+          have = true;
+        }
+        if (!have) {
+#pragma unroll
+          for (int o = -1; o <= 1; o += 2) {
+            const int oi = di ? 0 : o, oj = di ? o : 0;
+            const int c0 = __builtin_amdgcn_readlane(nbv, (1 + oi) * 3 + (1 + oj));
+            const int c1 = __builtin_amdgcn_readlane(nbv, (1 + oi + di) * 3 + (1 + oj + dj));
+            if (!have && c0 >= 0 && c1 >= 0) {
+              const int ex = (c1 & 0xFFFF) - (c0 & 0xFFFF), ey = (c1 >> 16) - (c0 >> 16);
+              predx = ax + ex; predy = ay + ey;
+              step2 = (long long)ex * ex + (long long)ey * ey;
+              have = true;
+            }
+          }
+        }
+        if (!have) {
+          const long long ex = di ? ux : vx, ey = di ? uy : vy;
+          const int sg = di ? di : dj;
+          predx = ax + sg * (int)ex; predy = ay + sg * (int)ey;
+          step2 = ex * ex + ey * ey;
+        }
+        long long dist = 0;
+        const int k = small ? nearest_free<true, J>(pxr, pyr, usedm, nk, lane, predx, predy, &dist) : nearest_free<false, J>(pxr, pyr, usedm, nk, lane, predx, predy, &dist);
+        if (k < 0) continue;
+        if (8 * dist > step2) continue;
+        const int packed = pick4<J>(pxr, k) | (pick4<J>(pyr, k) << 16);
+        put4<J>(qreg, qt, claim(k, ti, tj, packed), lane);
+        nbv = (lane == tc) ? packed : nbv;
+        ++qt;
+        ++L;
+      }
+    }
+    GTRACE(2); GTRACE_VAL(7, si * 1000 + L);
+    if (L != need) continue;
+    // un-shear: first k in 0,1,-1,2,-2,3,-3 whose (i + k*j, j) box is cols x rows or rows x cols.  The labelled cells are
+    // the cells of the used points (L of them), each in the lane that holds the point.
+    int found = 0, transpose = 0, imin = 0, jmin = 0, shear = 0;
+    int j0 = 1 << 20, j1 = -(1 << 20);
+#pragma unroll
+    for (int q = 0; q < J; ++q) if ((usedm >> q) & 1u) { const int jj = (cellr[q] >> 8) - GM; j0 = min(j0, jj); j1 = max(j1, jj); }
+    j0 = wave_min_i32(j0); j1 = wave_max_i32(j1);
+#pragma unroll 1
+    for (int t = 0; t < 7 && !found; ++t) {
+      const int k = (t == 0) ? 0 : ((t & 1) ? (t + 1) / 2 : -(t / 2));
+      int i0 = 1 << 20, i1 = -(1 << 20);
+#pragma unroll
+      for (int q = 0; q < J; ++q) if ((usedm >> q) & 1u) {
+        const int ii = (cellr[q] & 255) - GM, jj = (cellr[q] >> 8) - GM;
+        const int is = ii + k * jj;
+        i0 = min(i0, is); i1 = max(i1, is);
+      }
+      i0 = uni(wave_min_i32(i0)); i1 = uni(wave_max_i32(i1));
+      const int bw = i1 - i0 + 1, bh = uni(j1) - uni(j0) + 1;
+      if (bw == cols && bh == rows) { found = 1; transpose = 0; }
+      else if (bw == rows && bh == cols) { found = 1; transpose = 1; }
+      if (found) { imin = i0; jmin = uni(j0); shear = k; }
+    }
+    if (!found) continue;
+#pragma unroll
+    for (int q = 0; q < J; ++q) if ((usedm >> q) & 1u) {
+      const int ii = (cellr[q] & 255) - GM, jj = (cellr[q] >> 8) - GM;
+      const int a2 = ii + shear * jj - imin, bb = jj - jmin;
+      const int cc = transpose ? bb : a2, rr = transpose ? a2 : bb;
+      sm.tmp[rr * cols + cc] = (int16_t)(lane + 64 * q);
+    }
+    __syncthreads();
+    const int i00 = sm.tmp[0], ic = sm.tmp[cols - 1], ir = sm.tmp[(rows - 1) * cols];
+    const long long crs = (long long)(sm.px[ic] - sm.px[i00]) * (sm.py[ir] - sm.py[i00]) -
+                          (long long)(sm.py[ic] - sm.py[i00]) * (sm.px[ir] - sm.px[i00]);
+    const bool flipc = crs < 0;
+    for (int k = lane; k < need; k += 64) {
+      int r = k / cols, c = k - r * cols;
+      sm.t2[k] = sm.tmp[r * cols + (flipc ? cols - 1 - c : c)];
+    }
+    __syncthreads();
+    const int a0 = sm.t2[0], a1 = sm.t2[need - 1];
+    const bool rot = (sm.py[a1] < sm.py[a0]) || (sm.py[a1] == sm.py[a0] && sm.px[a1] < sm.px[a0]);
+    for (int k = lane; k < need; k += 64) sm.order[k] = rot ? sm.t2[need - 1 - k] : sm.t2[k];
+    __syncthreads();
+    found_board = true;
+  }
+  return found_board;
+}
+
 __device__ __forceinline__ bool index_frame(grid_smem& sm, const int f, const int lane, int w, int h,
                                             const rcc_cand* __restrict__ kept, const double* __restrict__ kept_xy,
                                             int target_kind, int cols, int rows, rcc_frame_corners* __restrict__ fc)
@@ -276,201 +486,7 @@ __device__ __forceinline__ bool index_frame(grid_smem& sm, const int f, const in
   bool found_board = false;
   if (target_kind == RCC_TARGET_CHECKERBOARD && nk >= need && nk <= RCC_MAX_KEPT && cols >= 2 && rows >= 2 &&
       cols <= GBOARD && rows <= GBOARD && need <= RCC_MAX_BOARD_CORNERS) {
-    int pxr[4], pyr[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = lane + 64 * j;
-      pxr[j] = (k < nk) ? sm.px[k] : 0;
-      pyr[j] = (k < nk) ? sm.py[k] : 0;
-    }
-    long long sx = 0, sy = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (lane + 64 * j < nk) { sx += pxr[j]; sy += pyr[j]; }
-    sx = wave_sum_i64(sx);
-    sy = wave_sum_i64(sy);
-    // seeds: the 8 points nearest the centroid, nearest first; seed s is kept in lane s of seedreg
-    unsigned takenm = 0;
-    int seedreg = 0;
-    const int nseeds = nk < 8 ? nk : 8;
-    for (int s = 0; s < nseeds; ++s) {
-      unsigned long long best = ~0ull;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = lane + 64 * j;
-        if (i < nk && !((takenm >> j) & 1u)) {
-          const long long ex = (long long)nk * pxr[j] - sx, ey = (long long)nk * pyr[j] - sy;
-          const unsigned long long key = ((unsigned long long)(ex * ex + ey * ey) << 8) | (unsigned long long)i;
-          best = key < best ? key : best;
-        }
-      }
-      best = wave_min_u64(best);
-      const int bi = uni((int)(best & 255ull));
-      if (lane == (bi & 63)) takenm |= 1u << (bi >> 6);
-      if (lane == s) seedreg = bi;
-    }
-    GTRACE(1);
-    // packed cell offsets of the 3 x 3 neighbourhood a lane < 9 reads: cell (i + lane / 3 - 1, j + lane % 3 - 1)
-    const int nb_off = (lane < 9) ? ((lane / 3 - 1) * GW + (lane % 3 - 1)) : 0;
-
-    for (int si = 0; si < nseeds && !found_board; ++si) {
-      const int s = uni(__builtin_amdgcn_readlane(seedreg, si));
-      __syncthreads();
-      for (int i = lane; i < GW * GW; i += 64) sm.labp[i] = -1;
-      unsigned usedm = (lane == (s & 63)) ? (1u << (s >> 6)) : 0u;
-      int cellr[4] = { 0, 0, 0, 0 };      // lattice cell (i + GM) | (j + GM) << 8 of the lane's points, where their used bit is set
-      int qreg[4] = { 0, 0, 0, 0 };       // the growth queue: entry e (a cell, packed as above) in lane e & 63 of register e >> 6
-      // give point k the cell (ti, tj): flags, the cell of the point, the label table (packed coordinates of the point)
-      auto claim = [&](const int k, const int ti, const int tj, const int packed_xy) {
-        const int cellp = (ti + GM) | ((tj + GM) << 8);
-        const bool mine = lane == (k & 63);
-        const int kj = k >> 6;
-        usedm |= mine ? (1u << kj) : 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cellr[j] = (mine && j == kj) ? cellp : cellr[j];
-        if (lane == 0) LABP(ti, tj) = packed_xy;
-        return cellp;
-      };
-      const int sxp = pick4(pxr, s), syp = pick4(pyr, s);
-      long long dd;
-      const int n1 = small ? nearest_free<true>(pxr, pyr, usedm, nk, lane, sxp, syp, &dd) : nearest_free<false>(pxr, pyr, usedm, nk, lane, sxp, syp, &dd);
-      if (n1 < 0) continue;
-      const int n1x = pick4(pxr, n1), n1y = pick4(pyr, n1);
-      const long long ux = n1x - sxp, uy = n1y - syp;
-      const long long uu = ux * ux + uy * uy;
-      unsigned long long best = ~0ull;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = lane + 64 * j;
-        if (k >= nk || k == s || k == n1) continue;
-        const long long wx = pxr[j] - sxp, wy = pyr[j] - syp;
-        const long long cr = ux * wy - uy * wx;
-        const long long wwv = wx * wx + wy * wy;
-        if (4 * cr * cr < uu * wwv) continue;
-        const unsigned long long key = ((unsigned long long)wwv << 8) | (unsigned long long)k;
-        best = key < best ? key : best;
-      }
-      best = wave_min_u64(best);
-      const unsigned blo = (unsigned)uni((int)(unsigned)best), bhi = (unsigned)uni((int)(unsigned)(best >> 32));
-      if (blo == ~0u && bhi == ~0u) continue;
-      const int n2 = (int)(blo & 255u);
-      const int n2x = pick4(pxr, n2), n2y = pick4(pyr, n2);
-      const long long vx = n2x - sxp, vy = n2y - syp;
-
-      put4(qreg, 0, claim(s, 0, 0, sxp | (syp << 16)), lane);
-      put4(qreg, 1, claim(n1, 1, 0, n1x | (n1y << 16)), lane);
-      put4(qreg, 2, claim(n2, 0, 1, n2x | (n2y << 16)), lane);
-      int qh = 0, qt = 3, L = 3;
-      __syncthreads();                 // the cleared table and the three labels are in place
-      GTRACE(3);
-      while (qh < qt) {
-        const int cell = pick4(qreg, qh);
-        ++qh;
-        const int i = (cell & 255) - GM, j = (cell >> 8) - GM;
-        // the 3 x 3 neighbourhood of (i, j) in ONE LDS round trip: lane c < 9 holds the packed coordinates of the point at
-        // cell (i + c / 3 - 1, j + c % 3 - 1), or -1.  Every rule below reads only these nine cells; a label set for
-        // direction d is patched into the register copy, so the later directions see it as the serial definition does.
-        int nbv = -1;
-        if (lane < 9) nbv = sm.labp[(i + GM) * GW + (j + GM) + nb_off];
-        const int a = __builtin_amdgcn_readlane(nbv, 4);
-        const int ax = a & 0xFFFF, ay = a >> 16;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const int di = (d == 0) ? 1 : (d == 1) ? -1 : 0;
-          const int dj = (d == 2) ? 1 : (d == 3) ? -1 : 0;
-          const int ti = i + di, tj = j + dj;
-          if (ti < -GM + 1 || ti > GM - 1 || tj < -GM + 1 || tj > GM - 1) continue;
-          const int tc = (1 + di) * 3 + (1 + dj);
-          if (__builtin_amdgcn_readlane(nbv, tc) >= 0) continue;
-          int predx = 0, predy = 0;
-          long long step2 = 0;
-          bool have = false;
-          const int opp = __builtin_amdgcn_readlane(nbv, (1 - di) * 3 + (1 - dj));
-          if (opp >= 0) {
-            const int bx = opp & 0xFFFF, by = opp >> 16;
-            predx = 2 * ax - bx; predy = 2 * ay - by;
-            step2 = (long long)(ax - bx) * (ax - bx) + (long long)(ay - by) * (ay - by);
-            have = true;
-          }
-          if (!have) {
-#pragma unroll
-            for (int o = -1; o <= 1; o += 2) {
-              const int oi = di ? 0 : o, oj = di ? o : 0;
-              const int c0 = __builtin_amdgcn_readlane(nbv, (1 + oi) * 3 + (1 + oj));
-              const int c1 = __builtin_amdgcn_readlane(nbv, (1 + oi + di) * 3 + (1 + oj + dj));
-              if (!have && c0 >= 0 && c1 >= 0) {
-                const int ex = (c1 & 0xFFFF) - (c0 & 0xFFFF), ey = (c1 >> 16) - (c0 >> 16);
-                predx = ax + ex; predy = ay + ey;
-                step2 = (long long)ex * ex + (long long)ey * ey;
-                have = true;
-              }
-            }
-          }
-          if (!have) {
-            const long long ex = di ? ux : vx, ey = di ? uy : vy;
-            const int sg = di ? di : dj;
-            predx = ax + sg * (int)ex; predy = ay + sg * (int)ey;
-            step2 = ex * ex + ey * ey;
-          }
-          long long dist = 0;
-          const int k = small ? nearest_free<true>(pxr, pyr, usedm, nk, lane, predx, predy, &dist) : nearest_free<false>(pxr, pyr, usedm, nk, lane, predx, predy, &dist);
-          if (k < 0) continue;
-          if (8 * dist > step2) continue;
-          const int packed = pick4(pxr, k) | (pick4(pyr, k) << 16);
-          put4(qreg, qt, claim(k, ti, tj, packed), lane);
-          nbv = (lane == tc) ? packed : nbv;
-          ++qt;
-          ++L;
-        }
-      }
-      GTRACE(2); GTRACE_VAL(7, si * 1000 + L);
-      if (L != need) continue;
-      // un-shear: first k in 0,1,-1,2,-2,3,-3 whose (i + k*j, j) box is cols x rows or rows x cols.  The labelled cells are
-      // the cells of the used points (L of them), each in the lane that holds the point.
-      int found = 0, transpose = 0, imin = 0, jmin = 0, shear = 0;
-      int j0 = 1 << 20, j1 = -(1 << 20);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if ((usedm >> q) & 1u) { const int jj = (cellr[q] >> 8) - GM; j0 = min(j0, jj); j1 = max(j1, jj); }
-      j0 = wave_min_i32(j0); j1 = wave_max_i32(j1);
-#pragma unroll 1
-      for (int t = 0; t < 7 && !found; ++t) {
-        const int k = (t == 0) ? 0 : ((t & 1) ? (t + 1) / 2 : -(t / 2));
-        int i0 = 1 << 20, i1 = -(1 << 20);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) if ((usedm >> q) & 1u) {
-          const int ii = (cellr[q] & 255) - GM, jj = (cellr[q] >> 8) - GM;
-          const int is = ii + k * jj;
-          i0 = min(i0, is); i1 = max(i1, is);
-        }
-        i0 = uni(wave_min_i32(i0)); i1 = uni(wave_max_i32(i1));
-        const int bw = i1 - i0 + 1, bh = uni(j1) - uni(j0) + 1;
-        if (bw == cols && bh == rows) { found = 1; transpose = 0; }
-        else if (bw == rows && bh == cols) { found = 1; transpose = 1; }
-        if (found) { imin = i0; jmin = uni(j0); shear = k; }
-      }
-      if (!found) continue;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) if ((usedm >> q) & 1u) {
-        const int ii = (cellr[q] & 255) - GM, jj = (cellr[q] >> 8) - GM;
-        const int a2 = ii + shear * jj - imin, bb = jj - jmin;
-        const int cc = transpose ? bb : a2, rr = transpose ? a2 : bb;
-        sm.tmp[rr * cols + cc] = (int16_t)(lane + 64 * q);
-      }
-      __syncthreads();
-      const int i00 = sm.tmp[0], ic = sm.tmp[cols - 1], ir = sm.tmp[(rows - 1) * cols];
-      const long long crs = (long long)(sm.px[ic] - sm.px[i00]) * (sm.py[ir] - sm.py[i00]) -
-                            (long long)(sm.py[ic] - sm.py[i00]) * (sm.px[ir] - sm.px[i00]);
-      const bool flipc = crs < 0;
-      for (int k = lane; k < need; k += 64) {
-        int r = k / cols, c = k - r * cols;
-        sm.t2[k] = sm.tmp[r * cols + (flipc ? cols - 1 - c : c)];
-      }
-      __syncthreads();
-      const int a0 = sm.t2[0], a1 = sm.t2[need - 1];
-      const bool rot = (sm.py[a1] < sm.py[a0]) || (sm.py[a1] == sm.py[a0] && sm.px[a1] < sm.px[a0]);
-      for (int k = lane; k < need; k += 64) sm.order[k] = rot ? sm.t2[need - 1 - k] : sm.t2[k];
-      __syncthreads();
-      found_board = true;
-    }
+    found_board = (nk <= 64) ? lattice_board<1>(sm, f, lane, nk, cols, rows, need, small) : lattice_board<4>(sm, f, lane, nk, cols, rows, need, small);
   }
   if (found_board) {
     for (int k = lane; k < need; k += 64) {
