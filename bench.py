@@ -46,6 +46,7 @@ def parse(argv=None):
     ap.add_argument("--ingest-variant", type=int, default=-1)
     ap.add_argument("--roofline-reps", type=int, default=5)
     ap.add_argument("--sync-steps", action="store_true", help="time K synchronous detect() calls instead of the submit/collect stream of K batches")
+    ap.add_argument("--sync-first", action="store_true", help="A/B of the order: run the synchronous comparison region BEFORE the streamed region that defines `value`")
     ap.add_argument("--pipeline", type=int, default=1, help="chunks of the detector's two-stream pipeline per step (1: single pass)")
     ap.add_argument("--fiducials", default="", help="BASELINE.json configs[4]-style run: GXxGY planar grid of square fiducials per frame, e.g. 6x4")
     ap.add_argument("--gather-side-stream", action="store_true", help="A/B: the per-step all_gather on a side stream instead of in line behind the batch")
@@ -102,6 +103,52 @@ def pin_to_gpu_numa(torch, local):
         return {"pci": bdf, "numa_node": node, "cpus": len(use)}
     except Exception:
         return None
+
+
+def sysfs_clocks(torch, local):
+    """current levels of the GPU's sysfs clock tables (pp_dpm_sclk / pp_dpm_mclk of the PCI device), where readable.  The engine
+    level is whatever the device idles at between two launches when the file is read -- the clock held INSIDE a kernel is the
+    issue probe's (out["clock"]["clock_mhz"]); the memory clock has one level on this part."""
+    out = {}
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        base = "/sys/bus/pci/devices/%04x:%02x:%02x.0/" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        for key, name in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+            try:
+                lines = [l.strip() for l in open(base + name)]
+            except OSError:
+                continue
+            cur = [l for l in lines if l.endswith("*")]
+            out[key + "_levels"] = lines
+            if cur:
+                out[key + "_mhz_current"] = float("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit() or ch == "."))
+    except Exception:
+        pass
+    return out
+
+
+def host_counters():
+    """what can stall the submitting thread without the device having anything to do with it: involuntary context switches of
+    this thread, and the cgroup's CPU-quota throttling counters (cpu.stat: nr_throttled, throttled_usec)"""
+    out = {}
+    try:
+        import resource
+        ru = resource.getrusage(getattr(resource, "RUSAGE_THREAD", resource.RUSAGE_SELF))
+        out["involuntary_ctx_switches"], out["voluntary_ctx_switches"] = ru.ru_nivcsw, ru.ru_nvcsw
+    except Exception:
+        pass
+    try:
+        for line in open("/sys/fs/cgroup/cpu.stat"):
+            k, _, v = line.partition(" ")
+            if k in ("nr_throttled", "throttled_usec", "nr_periods"):
+                out["cgroup_" + k] = int(v)
+    except Exception:
+        pass
+    try:
+        out["cpu"] = os.sched_getcpu()
+    except Exception:
+        pass
+    return out
 
 
 def rank_report(dist, dev, world, dt_local, steps, found_local, gather, pinned):
@@ -165,21 +212,29 @@ def workload_label(a, fid):
         a.batch, a.width, a.height, what, "fisheye" if a.fisheye else "plumb-bob", tag)
 
 
-def run_steps(det, frames, B, gather, steps, sync_steps):
+def run_steps(det, frames, B, gather, steps, sync_steps, want_corners=False):
     """The timed region's body: K steps of the whole path + the exchange of the records.  Works with any detector that
-    has detect / submit / collect (tests/test_dist_gloo.py drives it with a stand-in on CPU ranks)."""
+    has detect / submit / collect (tests/test_dist_gloo.py drives it with a stand-in on CPU ranks).
+    Leaves run_steps.trace: per step the wall-clock interval between consecutive results reaching the host
+    (`wall_ms`: step k = end of collect k-1 .. end of collect k; they add up to the region), and -- streaming form, from
+    the detector's HIP events -- the device time of the batch (`device_ms`), the device's idle time in front of it
+    (`idle_ms`: > 0 where the host submitted late) and the five stage times as they ran inside the step (`stages`)."""
     found = 0
     run_steps.local_found = 0        # records THIS rank produced in its last step (found: records visible after the exchange)
-    run_steps.dense_ms = []          # in-step duration of the threshold + corner launch of every streamed step (HIP events)
+    tr = run_steps.trace = {"wall_ms": [], "device_ms": [], "idle_ms": [], "stages": []}
     # ranks that exchange device-packed tables keep the detector on the stream the collective is ordered with, and count
     # the gathered records (a host synchronisation) only after the last step
     kw = {"stream": gather.stream} if getattr(gather, "stream", None) is not None else {}
+    t_prev = time.perf_counter()
     if sync_steps:
         for k in range(steps):
             getattr(gather, "before_submit", lambda s: None)(0)
-            dets, _ = det.detect(frames, B, want_corners=False, **kw)
+            dets, _ = det.detect(frames, B, want_corners=want_corners, **kw)
             run_steps.local_found = len(dets)
             found = gather.exchange(dets, 0, k == steps - 1)
+            t_now = time.perf_counter(); tr["wall_ms"].append(1e3 * (t_now - t_prev)); t_prev = t_now
+            if hasattr(det, "last_timings"):
+                tr["stages"].append(det.last_timings())
     else:
         # the streaming form of the same K steps (rcc_detect_batch_submit / _collect): batch k+1 is launched before
         # the host unpacks batch k, so the device does not idle during the unpack and the exchange of the records.
@@ -188,24 +243,55 @@ def run_steps(det, frames, B, gather, steps, sync_steps):
         before = getattr(gather, "before_submit", lambda s: None)
         # GPU ranks whose tables the detector packs: the collective is queued right behind the batch on the same stream
         inline = bool(getattr(gather, "inline", False) and getattr(gather, "attached", False) and gather.dist is not None)
+        skw = dict(kw, want_corners=True) if want_corners else kw
 
         def sub(slot):
-            before(slot); det.submit(frames, B, **kw)
+            before(slot); det.submit(frames, B, **skw)
             if inline:
                 gather.exchange(None, slot, False)
-        sub(slot_of_next); slot_of_next ^= 1
+        if steps > 0:
+            sub(slot_of_next); slot_of_next ^= 1
         for k in range(steps):
             if k + 1 < steps:
                 sub(slot_of_next); slot_of_next ^= 1
             dets, _ = det.collect()
             run_steps.local_found = len(dets)
-            if hasattr(det, "last_timings"):
-                run_steps.dense_ms.append(det.last_timings()["dense"])
             if inline:
                 found = gather.count() if k == steps - 1 else -1
             else:
                 found = gather.exchange(dets, getattr(det, "last_slot", 0), k == steps - 1)
+            t_now = time.perf_counter(); tr["wall_ms"].append(1e3 * (t_now - t_prev)); t_prev = t_now
+            if hasattr(det, "last_step_times"):
+                st = det.last_step_times()
+                tr["device_ms"].append(st.pop("device")); tr["idle_ms"].append(st.pop("idle_before")); tr["stages"].append(st)
     return found
+
+
+def trace_summary(tr, B, world=1):
+    """per-step figures of one timed region for the JSON line (this rank's own steps)"""
+    w = tr.get("wall_ms") or []
+    out = {"step_ms_all": [round(v, 4) for v in w]}
+    if w:
+        med = statistics.median(w)
+        out.update({"step_ms_median": med, "step_ms_min": min(w), "step_ms_max": max(w), "value_median": world * B / (med * 1e-3),
+                    "what": "wall clock between consecutive results reaching the host on rank 0 (they add up to the timed region); value_median = frames per step / median step -- `value` itself stays total frames / total time"})
+    if tr.get("device_ms"):
+        d, g = tr["device_ms"], tr["idle_ms"]
+        out["device_ms_all"] = [round(v, 4) for v in d]
+        out["device_idle_before_ms_all"] = [round(v, 4) for v in g]
+        out["device_ms_median"] = statistics.median(d)
+        late = [v for v in g if v > 0.02]
+        out["device_idle_total_ms"] = sum(v for v in g if v > 0)
+        out["steps_submitted_late"] = len(late)
+        out["device_what"] = "HIP events on the step's stream: device_ms = the stream reaches the batch -> its records are in pinned host memory; device_idle_before = end of the previous batch -> begin of this one (about 0 while the host keeps one batch ahead; > 0.02 ms counts as a late submission)"
+    if tr.get("host_during_region"):
+        out["host_during_region"] = tr["host_during_region"]
+        out["host_during_region_what"] = "rank 0's submitting thread over the K steps: context switches, the cgroup's quota-throttling counters (deltas), the CPU it ran on at both ends"
+    st = [x for x in (tr.get("stages") or []) if x and min(x.values()) >= 0]
+    if st:
+        out["stage_ms_mean"] = {k: sum(x[k] for x in st) / len(st) for k in st[0]}
+        out["stage_ms_median"] = {k: statistics.median(x[k] for x in st) for k in st[0]}
+    return out
 
 
 def host_cpus():
@@ -429,6 +515,16 @@ def main():
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (a.gpus, world))
         return 2
 
+    # thread pools (OpenMP / BLAS behind numpy and torch) size themselves by the CPUs they SEE; under a cgroup quota that is far
+    # more than the process may use, and a pool of spinning workers can eat the quota and get the whole process throttled
+    # for the rest of the scheduler period -- a multi-millisecond stall of the submitting thread.  Size them by what is usable.
+    ncpu_, quota_, model_ = host_cpus()
+    usable = max(1, min(ncpu_, quota_ or ncpu_))
+    pools = {}
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        pools[var] = os.environ.setdefault(var, str(usable))
+    host_info = {"cpu": model_, "cpus_visible": ncpu_, "cgroup_quota_cpus": quota_, "thread_pools": pools}
+
     import numpy as np
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU"
@@ -438,6 +534,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pinned = pin_to_gpu_numa(torch, local) if not a.no_pin else None
+    host_info["pinned"] = pinned
     dist = None
     if "WORLD_SIZE" in os.environ:          # launched by torchrun: the distributed path, whatever the world size (a world of
         import torch.distributed as dist    # one still runs the RCCL calls: init, barrier, all_gather of the record tables)
@@ -494,40 +591,53 @@ def main():
     if dist is not None:
         gather.attach(det, frame_offset=first)      # the detector packs the records on the device, every batch
 
-    run_steps(det, frames, B, gather, a.warmup, True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    gather.reset_timing()
-    t0 = time.perf_counter()
-    found = run_steps(det, frames, B, gather, a.steps, a.sync_steps)
-    dense_in_step = list(run_steps.dense_ms)
-    found_local = run_steps.local_found
-    torch.cuda.synchronize()
-    dt_local = time.perf_counter() - t0          # this rank's own K steps, before it waits for the others
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    ranks = rank_report(dist, dev, world, dt_local, a.steps, found_local, gather, pinned)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    # the same K steps as synchronous detect() calls, for comparison (reported, not `value`)
-    sync_fps = None
-    if not a.sync_steps:
+    def timed_region(sync_form, want_corners=False):
+        """W warm-up steps IN THE FORM THAT IS TIMED (so that the code paths, pinned slots and event rings of that form have all
+        been through once), barrier + synchronize, exactly K steps, synchronize + barrier; max over ranks."""
+        run_steps(det, frames, B, gather, a.warmup, sync_form, want_corners)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        t1s = time.perf_counter()
-        run_steps(det, frames, B, gather, a.steps, True)
+        gather.reset_timing()
+        hc0 = host_counters()
+        t0 = time.perf_counter()
+        fnd = run_steps(det, frames, B, gather, a.steps, sync_form, want_corners)
+        tr = run_steps.trace
+        fl = run_steps.local_found
         torch.cuda.synchronize()
+        dl = time.perf_counter() - t0          # this rank's own K steps, before it waits for the others
+        hc1 = host_counters()
+        tr["host_during_region"] = {k: (hc1[k] - hc0[k]) if k != "cpu" else [hc0[k], hc1[k]] for k in hc1 if k in hc0}
         if dist is not None:
             dist.barrier()
-        dts = torch.tensor([time.perf_counter() - t1s], dtype=torch.float64, device=dev)
+        d = time.perf_counter() - t0
+        rep = rank_report(dist, dev, world, dl, a.steps, fl, gather, pinned)
+        tmax = torch.tensor([d], dtype=torch.float64, device=dev)
         if dist is not None:
-            dist.all_reduce(dts, op=dist.ReduceOp.MAX)
-        sync_fps = world * B * a.steps / float(dts.item())
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return {"dt": float(tmax.item()), "found": fnd, "found_local": fl, "trace": tr, "ranks": rep}
+
+    # the region that defines `value` (streamed unless --sync-steps) and the other form for comparison; --sync-first swaps
+    # the order of the two (the first region after start-up meets whatever the device and the host have not ramped up yet)
+    regions = {}
+    order = [a.sync_steps] if a.sync_steps else ([True, False] if a.sync_first else [False, True])
+    for form in order:
+        regions[form] = timed_region(form)
+    main_r = regions[a.sync_steps]
+    dt, found, found_local, ranks = main_r["dt"], main_r["found"], main_r["found_local"], main_r["ranks"]
+    dense_in_step = [x["dense"] for x in main_r["trace"]["stages"] if x and x.get("dense", -1) > 0]
+    sync_fps = (world * B * a.steps / regions[True]["dt"]) if (True in regions and not a.sync_steps) else None
+    # the same streamed steps with the per-frame corner tables (rcc_frame_corners, 6 160 bytes per frame) copied back too
+    corner_r = timed_region(False, want_corners=True) if (not a.sync_steps and not a.no_extra_legs) else None
+    # the engine clock the chip holds under a vector-issue load, and what a vector wave-instruction costs, measured right
+    # behind the timed regions (rank 0)
+    clock = None
+    if rank == 0:
+        try:
+            clock = det.measure_clock(6, 20.0)
+            clock["sysfs"] = sysfs_clocks(torch, local)
+        except Exception as e:
+            clock = {"error": repr(e)}
     # per-stage times: one extra (untimed) step as a single pass on one stream -- in the pipelined step the stages of
     # different chunks overlap, so they have no separate durations
     prev = det.set_pipeline(1)
@@ -549,8 +659,17 @@ def main():
                        "target": ("%dx%d square fiducials of 0.10 m per frame (build family36b), corners by %s, 4-point PnP per tag" % (fid + ("refine_edges" if a.tag_refine == "edges" else "cornerSubPix",))) if fid else "8x6 inner-corner checkerboard, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
                        "parallelism": "frame-sharded, 1 process per GPU, 1 all_gather of pose records (19 doubles per target slot, packed on the device) per step"},
             "targets_found_in_last_step": int(found), "targets_expected_per_step": int(world * B * tpf), "stage_ms_single_pass": timings, "pipeline_chunks": a.pipeline, "step_form": "sync detect()" if a.sync_steps else "submit/collect, one batch ahead", "value_with_sync_steps": sync_fps,
-            "ranks": ranks,
+            "region_order": ["sync detect()" if f else "submit/collect" for f in order], "warmup_form": "the form that is timed (W steps in front of each region)",
+            "steps_trace": trace_summary(main_r["trace"], B, world),
+            "ranks": ranks, "host": host_info,
         }
+        if True in regions and not a.sync_steps:
+            out["sync_steps_trace"] = trace_summary(regions[True]["trace"], B, world)
+        if corner_r is not None:
+            out["value_with_corner_tables"] = {"value": world * B * a.steps / corner_r["dt"], "unit": "frames/s", "ms_per_step": 1e3 * corner_r["dt"] / a.steps,
+                                               "what": "the same K streamed steps with want_corners: every frame's rcc_frame_corners table (status, counts, 48 integer + 48 sub-pixel corners; %.1f MB per batch) copied to the host beside the records" % (B * 6160 / 1e6),
+                                               "steps_trace": trace_summary(corner_r["trace"], B, world)}
+        out["clock"] = clock
 
     # ---- roofline of the threshold+corner pass (the pass BASELINE.json's north_star names) AS THE STEP RUNS IT, and of
     # the ingest pass: algorithmic bytes / HIP-event time on the launch stream.  rcc_detect_batch leaves the binary image
@@ -587,8 +706,19 @@ def main():
             return None, "none"
         props = torch.cuda.get_device_properties(dev)
         simds = int(props.multi_processor_count) * 4
-        clock_mhz = float(getattr(props, "clock_rate", 2400000)) / 1e3
-        VALU_CYCLES = 4.4      # cycles per wave64 vector instruction per SIMD for this instruction mix at 6 waves per SIMD (profiles/r02_vbench.txt, r02_vbench_ilp.txt)
+        # cost of a vector wave-instruction per SIMD: measured in this process (out["clock"], k_probe.hip) -- the instruction
+        # classes of the pass at 6 waves per SIMD, ns from HIP events, the clock from s_memtime / s_memrealtime inside that
+        # kernel; the committed microbenchmark (4.4 cycles at the 2.4 GHz of the device properties) only if the probe failed
+        if clock and "ns_per_wave_inst_per_simd" in clock:
+            ns_inst, clock_mhz, cyc = clock["ns_per_wave_inst_per_simd"], clock["clock_mhz"], clock["cycles_per_wave_inst_per_simd"]
+            cost_src = "measured in this run behind the timed regions (rcc_debug_measure_clock: packed 16-bit / dot2 / perm / DPP / add3 loop, 6 waves per SIMD, %.1f ms launch; clock = d s_memtime / d s_memrealtime x 100 MHz, median over the waves)" % clock["probe_ms"]
+            clock_src = "measured in this run (in-kernel s_memtime / s_memrealtime of the issue probe)"
+        else:
+            clock_mhz = float(getattr(props, "clock_rate", 2400000)) / 1e3
+            cyc = 4.4
+            ns_inst = cyc / clock_mhz * 1e3
+            cost_src = "profiles/r02_vbench.txt, r02_vbench_ilp.txt (another box) at the clock of the device properties: NOT measured in this run"
+            clock_src = "device properties (nominal)"
 
         def issue_of(name, ms_launch):
             """the vector-issue roofline of the pass: SQ instruction counts of a committed profile x the measured issue cost"""
@@ -598,10 +728,10 @@ def main():
             try:
                 j = json.load(open(ipath))
                 valu, salu = float(j["valu_wave_insts_per_frame"]), float(j["salu_wave_insts_per_frame"])
-                bound_ms = valu * B * VALU_CYCLES / (simds * clock_mhz * 1e6) * 1e3
-                return {"valu_wave_insts_per_frame": valu, "salu_wave_insts_per_frame": salu, "cycles_per_inst": VALU_CYCLES,
-                        "cycles_per_inst_source": "profiles/r02_vbench.txt, r02_vbench_ilp.txt: packed 16-bit / dot2 / DPP / perm / compare classes at 6 waves per SIMD",
-                        "simds": simds, "clock_mhz": clock_mhz, "issue_bound_ms": bound_ms, "frac_of_issue_bound": bound_ms / ms_launch,
+                bound_ms = valu * B * ns_inst / simds * 1e-6
+                return {"valu_wave_insts_per_frame": valu, "salu_wave_insts_per_frame": salu, "ns_per_inst": ns_inst, "cycles_per_inst": cyc,
+                        "cycles_per_inst_source": cost_src,
+                        "simds": simds, "clock_mhz": clock_mhz, "clock_source": clock_src, "issue_bound_ms": bound_ms, "frac_of_issue_bound": bound_ms / ms_launch,
                         "source": "profiles/%s <- profiles/%s: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU of %s on an earlier run of this code, scaled per frame; not measured in this run" % (name, j.get("source"), j.get("kernel"))}
             except Exception:
                 return None

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define RCC_ABI_VERSION 1
+#define RCC_ABI_VERSION 2
 
 /* ---- status codes -------------------------------------------------------------------------- */
 enum {
@@ -286,7 +286,23 @@ typedef struct rcc_synth_params {
   int32_t  fid_grid_x, fid_grid_y;  /* > 0: render a planar grid of fiducials (ids 0..) instead of the board */
   int32_t  fid_gap_permille;        /* white gap between tags, in 1/1000 of the tag size (500) */
   int32_t  reserved[2];
+  /* ---- optics (ABI 2).  All zero = the ideal camera of ABI 1, bit for bit.  The real input is a webcam through cv_camera
+   * (real_preprocessing/README.md:25,64-65): its images are not razor-edged.  Everything here is INTEGER arithmetic on the
+   * supersampled image (the sum of the s x s integer samples of a pixel), applied before the sensor noise:
+   *   blur:      separable, symmetric; blur_taps[k] = weight at distance k (k = 0..RCC_SYNTH_BLUR_TAPS-1), and
+   *              blur_taps[0] + 2 * sum(blur_taps[1..]) must be 256 (or all zero: no blur); rows and columns are clamped at the
+   *              image border.  {128, 64} is the 3-tap 1-2-1 filter; rcc_synth_gaussian_taps() in abi.py fills a Gaussian.
+   *   shading:   gain(u, v) in 1/4096: lin = 4096 + trunc(4096 * (gx * X + gy * Y) / 1000), X = (2u - (w-1)) / (w-1) in [-1, 1]
+   *              (shade_x_permille = gx: relative brightness change from the centre to the right edge), Y alike;
+   *              vig = 4096 - trunc(4096 * vignette_permille * r2 / (1000 * R2)), r2 = (2u-(w-1))^2 + (2v-(h-1))^2, R2 its value in
+   *              a corner (vignette_permille = relative darkening of the corners); gain = lin * vig >> 12.
+   *   pixel = rint(blurred * gain / (256 * 256 * 4096 * s * s) + noise), clamped to [0, 255]. */
+  int32_t  blur_taps[8];
+  int32_t  shade_x_permille, shade_y_permille;
+  int32_t  vignette_permille;
+  int32_t  reserved2[1];
 } rcc_synth_params;
+#define RCC_SYNTH_BLUR_TAPS 8
 
 /* Render nframes frames of the handle's geometry/intrinsics into d_frames (device), one pose per
  * frame: poses = nframes x 6 doubles (rvec, tvec of cam_T_target), host memory. */

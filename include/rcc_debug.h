@@ -55,10 +55,22 @@ int rcc_set_pnp_variant(rcc_handle* h, int variant);
 
 /* ---- timers (HIP events on the launch stream) ------------------------------------------------------------------------ */
 /* stage times of the last synchronous rcc_detect_batch / stage call, ms: [0] ingest, [1] threshold+corner,
- * [2] list + sub-pixel (+ grid when not fused), [3] pose (+ grid when fused), [4] d2h (-1 where not recorded: after
- * rcc_detect_batch_collect only [1] is set -- the threshold + corner launch as it ran inside that step).  Returns the
- * slots written. */
+ * [2] list + sub-pixel (+ grid when not fused), [3] pose (+ grid when fused), [4] d2h (-1 where not recorded: a chunked
+ * batch has no separate stage durations).  After rcc_detect_batch_collect: the stages as they ran inside that streamed
+ * step.  Returns the slots written. */
 int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n);
+/* the batch rcc_detect_batch_collect just handed back, ms: [0] device time from the moment its stream reached the batch
+ * to its records lying in pinned host memory, [1] device idle time in front of it (end of the previous submission ->
+ * begin of this one; ~0 while the host keeps a batch ahead, > 0 where the host submitted late; -1 for the first
+ * submission), [2..6] = the five stage times of rcc_last_timings.  Returns the slots written. */
+int rcc_last_step_times(const rcc_handle* h, float* ms, int32_t n);
+/* the engine clock this device holds under a vector-issue load and the cost of one vector wave-instruction, measured by
+ * this call (k_probe.hip): a launch of about ms_target milliseconds of the threshold + corner pass's instruction classes
+ * (packed 16-bit, dot2, perm, DPP, three-operand adds) at waves_per_simd waves per SIMD on every CU.
+ * out6: [0] clock in MHz (delta s_memtime / delta s_memrealtime x 100 MHz, median over the waves), [1] ns per
+ * wave-instruction per SIMD (HIP events around the launch), [2] = [1] x [0] cycles, [3] ms of the launch, [4] / [5]
+ * lowest / highest clock any wave saw. */
+int rcc_debug_measure_clock(rcc_handle* h, int32_t waves_per_simd, float ms_target, double* out6);
 /* name(s) of the kernel(s) the last threshold + corner launch used, as rocprofv3's kernel trace prints them */
 const char* rcc_last_dense_kernel(const rcc_handle* h);
 /* mean ms of `reps` back-to-back launches of the threshold + corner pass.  d_bin == NULL: the form rcc_detect_batch

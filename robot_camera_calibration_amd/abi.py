@@ -6,7 +6,7 @@ The reference interface each entry point stands in for is cited in include/rcc.h
 """
 import ctypes as C
 
-RCC_ABI_VERSION = 1
+RCC_ABI_VERSION = 2
 
 # status
 RCC_OK, RCC_ERR_ARG, RCC_ERR_UNSUPPORTED, RCC_ERR_DEVICE, RCC_ERR_CAPACITY, RCC_ERR_NOMEM, RCC_ERR_STATE = 0, -1, -2, -3, -4, -5, -6
@@ -77,6 +77,10 @@ class rcc_synth_params(C.Structure):
         ("black", C.c_int32), ("white", C.c_int32), ("background", C.c_int32),
         ("fid_grid_x", C.c_int32), ("fid_grid_y", C.c_int32), ("fid_gap_permille", C.c_int32),
         ("reserved", C.c_int32 * 2),
+        ("blur_taps", C.c_int32 * 8),
+        ("shade_x_permille", C.c_int32), ("shade_y_permille", C.c_int32),
+        ("vignette_permille", C.c_int32),
+        ("reserved2", C.c_int32 * 1),
     ]
 
 
@@ -92,6 +96,46 @@ def default_synth_params(cols=8, rows=6, square=0.108, seed=0xC0FFEE, noise=2.0,
     sp.margin_squares, sp.supersample, sp.noise_sigma = 1, supersample, noise
     sp.seed = seed
     sp.black, sp.white, sp.background = 20, 235, 128
+    return sp
+
+
+RCC_SYNTH_BLUR_TAPS = 8
+
+
+def gaussian_taps(sigma):
+    """Integer half-kernel of a Gaussian of standard deviation sigma (pixels) for rcc_synth_params.blur_taps: weight at
+    distance k = 0..7, radius ceil(3 sigma) (at most 7), with taps[0] + 2 * sum(taps[1:]) == 256 exactly (largest-remainder
+    rounding; the centre tap takes what symmetry leaves over).  sigma <= 0: no blur (all zero)."""
+    import math
+    taps = [0] * RCC_SYNTH_BLUR_TAPS
+    if not sigma or sigma <= 0:
+        return taps
+    r = min(RCC_SYNTH_BLUR_TAPS - 1, int(math.ceil(3.0 * sigma)))
+    w = [math.exp(-0.5 * (k / sigma) ** 2) for k in range(r + 1)]
+    tot = w[0] + 2.0 * sum(w[1:])
+    for k in range(1, r + 1):
+        taps[k] = int(math.floor(256.0 * w[k] / tot + 0.5))
+    taps[0] = 256 - 2 * sum(taps[1:])
+    assert taps[0] > 0
+    return taps
+
+
+BLUR_3TAP = [128, 64, 0, 0, 0, 0, 0, 0]       # the 1-2-1 filter of SURVEY.md 8(d) ("optional 3-tap blur")
+
+
+def set_optics(sp, blur=None, shade_x=0, shade_y=0, vignette=0):
+    """blur: None / 0 (off), "3tap", a Gaussian sigma in pixels, or a list of 8 integer taps; shading in permille"""
+    if blur is None or blur == 0:
+        taps = [0] * RCC_SYNTH_BLUR_TAPS
+    elif blur == "3tap":
+        taps = BLUR_3TAP
+    elif isinstance(blur, (int, float)):
+        taps = gaussian_taps(float(blur))
+    else:
+        taps = list(blur) + [0] * (RCC_SYNTH_BLUR_TAPS - len(blur))
+    for k in range(RCC_SYNTH_BLUR_TAPS):
+        sp.blur_taps[k] = int(taps[k])
+    sp.shade_x_permille, sp.shade_y_permille, sp.vignette_permille = int(shade_x), int(shade_y), int(vignette)
     return sp
 
 

@@ -99,6 +99,10 @@ def load_library():
     L.rcc_set_pipeline.restype = C.c_int
     L.rcc_set_pnp_variant.restype = C.c_int
     L.rcc_last_timings.argtypes = [P, P, I]
+    L.rcc_last_step_times.argtypes = [P, P, I]
+    L.rcc_last_step_times.restype = C.c_int
+    L.rcc_debug_measure_clock.argtypes = [P, I, C.c_float, P]
+    L.rcc_debug_measure_clock.restype = C.c_int
     L.rcc_time_dense.argtypes = [P, P, I, P, P, P, I, C.POINTER(C.c_float)]
     L.rcc_time_ingest.argtypes = [P, P, I, P, I, C.POINTER(C.c_float)]
     L.rcc_synth_render_batch.argtypes = [P, C.POINTER(abi.rcc_synth_params), P, I, I, P, P]
@@ -136,7 +140,7 @@ EXPORTED_SYMBOLS = (
 # include/rcc_debug.h: test taps, timers, A/B switches between bit-identical variants (not part of the boundary)
 DEBUG_EXPORTED_SYMBOLS = (
     "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_set_dense_skip", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline", "rcc_set_host_chunk", "rcc_set_dense_gang", "rcc_set_subpix_grid",
-    "rcc_set_pnp_variant", "rcc_last_timings", "rcc_last_dense_kernel", "rcc_time_dense", "rcc_time_ingest", "rcc_time_copy",
+    "rcc_set_pnp_variant", "rcc_last_timings", "rcc_last_step_times", "rcc_debug_measure_clock", "rcc_last_dense_kernel", "rcc_time_dense", "rcc_time_ingest", "rcc_time_copy",
     "rcc_debug_calib_copy", "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_debug_pnp_probe",
 )
 # include/rcc_dist.h (librcc_dist.so: the RCCL all-gather of the record tables for non-Python hosts)
@@ -405,6 +409,20 @@ class Detector:
         ms = (C.c_float * 5)()
         self._L.rcc_last_timings(self._h, ms, 5)
         return dict(zip(("ingest", "dense", "list_subpix_grid", "pnp", "d2h"), [float(v) for v in ms]))
+
+    def last_step_times(self):
+        """the batch collect() just handed back, ms: device time (stream reaches the batch -> records in pinned memory), device
+        idle time in front of it (-1: unknown), and the five stage times as they ran inside that streamed step"""
+        ms = (C.c_float * 7)()
+        self._L.rcc_last_step_times(self._h, ms, 7)
+        return dict(zip(("device", "idle_before", "ingest", "dense", "list_subpix_grid", "pnp", "d2h"), [float(v) for v in ms]))
+
+    def measure_clock(self, waves_per_simd=6, ms_target=20.0):
+        """engine clock held under a vector-issue load and the cost of a vector wave-instruction, measured now (k_probe.hip)"""
+        out = (C.c_double * 6)()
+        self._chk(self._L.rcc_debug_measure_clock(self._h, int(waves_per_simd), float(ms_target), out), "rcc_debug_measure_clock")
+        return dict(clock_mhz=out[0], ns_per_wave_inst_per_simd=out[1], cycles_per_wave_inst_per_simd=out[2], probe_ms=out[3],
+                    clock_mhz_min=out[4], clock_mhz_max=out[5], waves_per_simd=int(waves_per_simd))
 
     def last_dense_kernel(self):
         return self._L.rcc_last_dense_kernel(self._h).decode()

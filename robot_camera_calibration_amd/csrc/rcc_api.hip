@@ -12,6 +12,7 @@
 #include <cstring>
 #include <cmath>
 #include <new>
+#include <algorithm>
 #include <vector>
 #include "rcc_internal.h"
 #include "../../include/rcc_debug.h"
@@ -125,7 +126,7 @@ void rcc_destroy(rcc_handle* h)
   if (h->h_det2) (void)hipHostFree(h->h_det2);
   if (h->h_ndet2) (void)hipHostFree(h->h_ndet2);
   for (auto& e : h->sub_ev) if (e) (void)hipEventDestroy(e);
-  for (auto& p : h->sub_dense_ev) for (auto& e : p) if (e) (void)hipEventDestroy(e);
+  for (auto& p : h->sub_t_ev) for (auto& e : p) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   for (auto& ps : h->pstream) if (ps) (void)hipStreamDestroy(ps);
@@ -206,7 +207,8 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
       hipHostMalloc((void**)&h->h_det2, B * (size_t)cfg->max_targets * sizeof(rcc_detection)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_ndet2, B * sizeof(int32_t)) != hipSuccess) { rcc_destroy(h); return RCC_ERR_NOMEM; }
   for (auto& e : h->sub_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
-  for (auto& p : h->sub_dense_ev) for (auto& e : p) if (hipEventCreate(&e) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
+  for (auto& p : h->sub_t_ev) for (auto& e : p) if (hipEventCreate(&e) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
+  for (float& m : h->last_step_ms) m = -1.0f;
   {
     // object points of the board: index = row*cols + col, x right, y up, z = 0, origin at the
     // centre -- the object-frame convention of camera_pose.cpp:158-161
@@ -337,6 +339,14 @@ int rcc_last_timings(const rcc_handle* h, float* ms, int32_t n)
   return k;
 }
 
+int rcc_last_step_times(const rcc_handle* h, float* ms, int32_t n)
+{
+  if (!h || !ms) return RCC_ERR_ARG;
+  int k = n < 7 ? n : 7;
+  for (int i = 0; i < k; ++i) ms[i] = h->last_step_ms[i];
+  return k;
+}
+
 static bool records_fit(const rcc_handle* h, int nframes);
 
 // ---- stages ------------------------------------------------------------------------------------
@@ -403,21 +413,23 @@ int rcc_time_ingest(rcc_handle* h, const void* d_frames, int32_t nframes, void* 
 
 // list + subpix + validate/grid + pnp, then results to the host.  Events: ev[2]..ev[5].
 // list -> sub-pixel -> target identification -> pose, for the frames the (possibly offset) handle view covers
+// tev: three timing events (recorded in front of the list stage, behind the sub-pixel / quad stage, behind the pose stage) or NULL
 static int launch_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, const rcc_cand* d_cand,
-                          const int32_t* d_cand_count, int nframes, hipStream_t s, bool timed)
+                          const int32_t* d_cand_count, int nframes, hipStream_t s, hipEvent_t* tev)
 {
   const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
-  if (timed) HIPCHK(h, hipEventRecord(h->ev[2], s));
+  const bool timed = tev != nullptr;
+  if (timed) HIPCHK(h, hipEventRecord(tev[0], s));
   HIPCHK(h, rcc_launch_list(h, d_cand, d_cand_count, nframes, s));
   HIPCHK(h, rcc_launch_subpix(h, d_grey, nframes, s));
   const bool fused = !fid && h->fuse_grid_pnp && rcc_grid_pnp_applicable(h);   // lattice indexing + pose in one launch
   if (fid) HIPCHK(h, rcc_launch_fid(h, d_grey, nframes, s));
   else if (!fused) HIPCHK(h, rcc_launch_grid(h, d_grey, d_bin, nframes, s));
-  if (timed) HIPCHK(h, hipEventRecord(h->ev[3], s));
+  if (timed) HIPCHK(h, hipEventRecord(tev[1], s));
   if (fid) HIPCHK(h, rcc_launch_pnp_tags(h, nframes, s));
   else if (fused) HIPCHK(h, rcc_launch_grid_pnp(h, d_grey, d_bin, nframes, s));
   else HIPCHK(h, rcc_launch_pnp_board(h, nframes, s));
-  if (timed) HIPCHK(h, hipEventRecord(h->ev[4], s));
+  if (timed) HIPCHK(h, hipEventRecord(tev[2], s));
   return RCC_OK;
 }
 
@@ -453,7 +465,7 @@ static int run_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bi
                        const int32_t* d_cand_count, int nframes, rcc_detection* det, int32_t* ndet,
                        rcc_frame_corners* corners, hipStream_t s)
 {
-  int r = launch_targets(h, d_grey, d_bin, d_cand, d_cand_count, nframes, s, true);
+  int r = launch_targets(h, d_grey, d_bin, d_cand, d_cand_count, nframes, s, &h->ev[2]);
   if (r != RCC_OK) return r;
   return collect_targets(h, nframes, det, ndet, corners, s, true);
 }
@@ -546,7 +558,7 @@ static int launch_host_pipeline(rcc_handle* h, const uint8_t* host_frames, int n
     if (e == hipSuccess) e = rcc_launch_dense(&v, v.d_grey, f1 - f0, v.d_bin, v.d_cand, v.d_cand_count, s);
     if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s", hipGetErrorString(e)); return RCC_ERR_DEVICE; }
     h->dense_kernel = v.dense_kernel;
-    int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, s, false);
+    int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, s, nullptr);
     if (r != RCC_OK) { snprintf(h->err, sizeof(h->err), "%s", v.err); return r; }
     h->bin_from_thr = v.bin_from_thr;
   }
@@ -603,7 +615,7 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
       h->d_map = v.d_map; h->d_tilebox = v.d_tilebox; h->map_failed = v.map_failed;     // tables built by the first launch belong to the handle
       if (e == hipSuccess) e = rcc_launch_dense(&v, v.d_grey, f1 - f0, v.d_bin, v.d_cand, v.d_cand_count, cs);
       if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s", hipGetErrorString(e)); return RCC_ERR_DEVICE; }
-      int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, cs, false);
+      int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, cs, nullptr);
       if (r != RCC_OK) { snprintf(h->err, sizeof(h->err), "%s", v.err); return r; }
       h->bin_from_thr = v.bin_from_thr;
     }
@@ -623,7 +635,7 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
   h->want_thr = h->keep_bin ? 0 : 1;
   HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
   h->want_thr = 0;
-  int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, true);
+  int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, &h->ev[2]);
   if (r != RCC_OK) return r;
   if (h->rec_table[0]) HIPCHK(h, rcc_launch_pack_records(h, nframes, h->rec_offset, h->rec_table[0], s));
   r = collect_targets(h, nframes, det, ndet, corners, s, true);
@@ -648,12 +660,16 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   if (h->sub_head != h->sub_tail && h->sub_stream[(h->sub_head - 1) & 1u] != s) return RCC_ERR_STATE;
   if (detect_needs_bin(h)) { int rb = ensure_bin(h); if (rb != RCC_OK) return rb; }
   const int slot = (int)(h->sub_head & 1u);
+  const int ring = (int)(h->sub_head % RCC_SUBT_RING);
+  hipEvent_t* tev = h->sub_t_ev[ring];
+  h->sub_t_seq[ring] = 0;
   const uint8_t* d_frames = (const uint8_t*)frames;
   bool piped = false;
   if (frames_mem == RCC_MEM_HOST) {
     { int rs = ensure_stage(h, (size_t)h->cfg.frame_bytes * nframes, h->sub_head == h->sub_tail); if (rs != RCC_OK) return rs; }
     const int per = host_chunk_frames(h, nframes);
     if (per > 0) {
+      HIPCHK(h, hipEventRecord(tev[0], s));
       int r = launch_host_pipeline(h, (const uint8_t*)frames, nframes, per, s);
       if (r != RCC_OK) return r;
       piped = true;
@@ -664,17 +680,14 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   }
   const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
   const int slots = h->cfg.max_targets;
-  if (piped) {
-    HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][0], s));       // (no separate duration for the pass in this form)
-    HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][1], s));
-  } else {
+  if (!piped) {
+    HIPCHK(h, hipEventRecord(tev[0], s));
     HIPCHK(h, rcc_launch_ingest(h, d_frames, nframes, h->d_grey, s));
+    HIPCHK(h, hipEventRecord(tev[1], s));
     h->want_thr = h->keep_bin ? 0 : 1;
-    HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][0], s));
     HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
-    HIPCHK(h, hipEventRecord(h->sub_dense_ev[slot][1], s));
     h->want_thr = 0;
-    int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, false);
+    int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, &tev[2]);
     if (r != RCC_OK) return r;
   }
   if (h->rec_table[slot]) HIPCHK(h, rcc_launch_pack_records(h, nframes, h->rec_offset, h->rec_table[slot], s));
@@ -683,7 +696,11 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   HIPCHK(h, hipMemcpyAsync(hd, h->d_det, sizeof(rcc_detection) * (size_t)nframes * (fid ? slots : 1), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(hn, h->d_ndet, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost, s));
   if (corners) HIPCHK(h, hipMemcpyAsync(corners, h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipEventRecord(tev[5], s));
   HIPCHK(h, hipEventRecord(h->sub_ev[slot], s));
+  h->sub_t_seq[ring] = h->sub_head + 1u;
+  h->sub_t_staged[ring] = piped ? 0 : 1;
+  h->sub_t_stream[ring] = s;
   h->sub_nframes[slot] = nframes;
   h->sub_stream[slot] = s;
   ++h->sub_head;
@@ -712,8 +729,26 @@ int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet)
     }
   }
   if (ndet) *ndet = n;
-  // the one stage time the streaming form records: the threshold + corner launch as it ran INSIDE this step
-  (void)hipEventElapsedTime(&h->last_ms[1], h->sub_dense_ev[slot][0], h->sub_dense_ev[slot][1]);
+  // what the streaming form records per batch: the device time from the moment the stream reached it to its records in pinned
+  // memory, the device's idle time in front of it (> 0: the host submitted late), and the stages as they ran INSIDE this step
+  {
+    const unsigned sn = h->sub_tail;
+    const int ring = (int)(sn % RCC_SUBT_RING), prev = (int)((sn + RCC_SUBT_RING - 1) % RCC_SUBT_RING);
+    for (float& m : h->last_step_ms) m = -1.0f;
+    if (h->sub_t_seq[ring] == sn + 1u) {
+      hipEvent_t* tev = h->sub_t_ev[ring];
+      if (hipEventElapsedTime(&h->last_step_ms[0], tev[0], tev[5]) != hipSuccess) h->last_step_ms[0] = -1.0f;
+      if (sn > 0 && h->sub_t_seq[prev] == sn && h->sub_stream[slot] == h->sub_t_stream[prev]) {
+        if (hipEventElapsedTime(&h->last_step_ms[1], h->sub_t_ev[prev][5], tev[0]) != hipSuccess) h->last_step_ms[1] = -1.0f;
+      }
+      if (h->sub_t_staged[ring])
+        for (int i = 0; i < 5; ++i) {
+          if (hipEventElapsedTime(&h->last_step_ms[2 + i], tev[i], tev[i + 1]) != hipSuccess) h->last_step_ms[2 + i] = -1.0f;
+          h->last_ms[i] = h->last_step_ms[2 + i];
+        }
+    }
+    (void)hipGetLastError();
+  }
   h->sub_nframes[slot] = 0;
   ++h->sub_tail;
   return RCC_OK;
@@ -841,6 +876,57 @@ int rcc_time_copy(rcc_handle* h, const void* d_src, void* d_dst, int64_t nbytes,
   float ms = 0.0f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev[6], h->ev[7]));
   *mean_ms = ms / (float)reps;
+  return RCC_OK;
+}
+
+// measurement aid (k_probe.hip): the engine clock the chip holds under a vector-issue load and what a wave-instruction of the
+// threshold + corner pass's instruction classes costs per SIMD, measured on this device by this call
+int rcc_debug_measure_clock(rcc_handle* h, int32_t waves_per_simd, float ms_target, double* out6)
+{
+  if (!h || !out6 || waves_per_simd < 1 || waves_per_simd > 8 || !(ms_target > 0.0f) || ms_target > 1000.0f) return RCC_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipDeviceProp_t pr;
+  HIPCHK(h, hipGetDeviceProperties(&pr, h->device));
+  const int blocks = pr.multiProcessorCount * waves_per_simd;       // 256 threads = four waves = one per SIMD of a CU
+  const size_t nw = (size_t)blocks * 4;
+  unsigned long long* d_st = nullptr;
+  unsigned* d_sink = nullptr;
+  if (hipMalloc((void**)&d_st, nw * 2 * sizeof(unsigned long long)) != hipSuccess) return RCC_ERR_NOMEM;
+  if (hipMalloc((void**)&d_sink, 64) != hipSuccess) { (void)hipFree(d_st); return RCC_ERR_NOMEM; }
+  hipStream_t s = h->stream;
+  int rc = RCC_OK;
+  float ms = 0.0f;
+  int iters = 256;
+  std::vector<unsigned long long> st(nw * 2);
+  auto run = [&](int it) -> bool {
+    return hipEventRecord(h->ev[6], s) == hipSuccess && rcc_launch_issue_probe(blocks, it, d_st, d_sink, s) == hipSuccess &&
+           hipEventRecord(h->ev[7], s) == hipSuccess && hipEventSynchronize(h->ev[7]) == hipSuccess &&
+           hipEventElapsedTime(&ms, h->ev[6], h->ev[7]) == hipSuccess;
+  };
+  if (!run(iters) || !run(iters)) rc = RCC_ERR_DEVICE;                 // the second launch sizes the measured one
+  if (rc == RCC_OK) {
+    double want = (double)iters * (double)ms_target / (ms > 1e-3f ? ms : 1e-3f);
+    if (want < 64.0) want = 64.0;
+    if (want > 4.0e6) want = 4.0e6;
+    iters = (int)want;
+    if (!run(iters) || hipMemcpy(st.data(), d_st, nw * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = RCC_ERR_DEVICE;
+  }
+  (void)hipFree(d_st);
+  (void)hipFree(d_sink);
+  if (rc != RCC_OK) { snprintf(h->err, sizeof(h->err), "issue probe: %s", hipGetErrorString(hipGetLastError())); return rc; }
+  std::vector<double> mhz;
+  mhz.reserve(nw);
+  for (size_t w = 0; w < nw; ++w)
+    if (st[2 * w + 1] > 0) mhz.push_back(100.0 * (double)st[2 * w] / (double)st[2 * w + 1]);   // s_memrealtime ticks at 100 MHz
+  if (mhz.empty()) return RCC_ERR_DEVICE;
+  std::sort(mhz.begin(), mhz.end());
+  const double ns = (double)ms * 1e6 / ((double)iters * RCC_PROBE_INSTS_PER_ITER * (double)waves_per_simd);
+  out6[0] = mhz[mhz.size() / 2];
+  out6[1] = ns;
+  out6[2] = ns * 1e-3 * out6[0];
+  out6[3] = (double)ms;
+  out6[4] = mhz.front();
+  out6[5] = mhz.back();
   return RCC_OK;
 }
 

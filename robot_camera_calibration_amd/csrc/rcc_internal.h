@@ -11,6 +11,8 @@
 #define RCC_THR_PITCH 512     // bytes per tile row of one band in the compact threshold map (480 used at 1920 columns)
 #define RCC_BAND_W 1920        // output columns per band of the band kernel
 #define RCC_HOST_CHUNKS 64      // at most this many chunks per host-resident batch
+#define RCC_SUBT_RING 4          // submissions whose timing events are kept (rcc_detect_batch_submit)
+#define RCC_PROBE_INSTS_PER_ITER 64   // k_probe.hip: vector instructions per loop iteration of the issue probe
 
 // Flat masks of the two-kernel threshold + corner pass (k_dense_band.hip sweep -> k_dense_runs.hip): one 64-bit word per
 // (frame, band, window of the band, tile row): bit l = lane l's 4x4 tile has a dilated contrast below min_contrast.
@@ -98,7 +100,15 @@ struct rcc_handle {
   rcc_detection* h_det2;
   int32_t* h_ndet2;
   hipEvent_t sub_ev[2];     // results of the submission in slot i are in pinned memory
-  hipEvent_t sub_dense_ev[2][2];   // around the threshold + corner launch of the submission in slot i (its in-step duration)
+  // timing events of the streaming form, a ring over the last RCC_SUBT_RING submissions (submission n uses entry n mod ring, so the
+  // previous submission's end is still readable when this one is collected): [0] the stream reaches the batch, [1] ingest done,
+  // [2] threshold + corner pass done, [3] list + sub-pixel (+ quads) done, [4] pose done, [5] records in pinned host memory
+  hipEvent_t sub_t_ev[RCC_SUBT_RING][6];
+  unsigned sub_t_seq[RCC_SUBT_RING];     // submission number + 1 whose events the entry holds (0: none)
+  hipStream_t sub_t_stream[RCC_SUBT_RING];
+  unsigned char sub_t_staged[RCC_SUBT_RING];   // 1: stage events [1..4] were recorded (0: chunked host-input pipeline, only [0] and [5])
+  float last_step_ms[7];    // after rcc_detect_batch_collect: [0] device time of that batch (events 0 -> 5), [1] device idle in front of it
+                            // (previous submission's [5] -> this [0]; -1 unknown), [2..6] ingest, threshold + corner, list + sub-pixel, pose, d2h
   int sub_nframes[2];       // frames of the submission in slot i (0: slot free)
   hipStream_t sub_stream[2];
   unsigned sub_head, sub_tail;   // submissions issued / collected
@@ -175,6 +185,7 @@ hipError_t rcc_launch_pnp_generic(rcc_handle* h, const double* d_obj, const doub
 hipError_t rcc_launch_pnp_probe(const double* d_obj, const double* d_img, int n, rcc_cam cam, double* d_out, hipStream_t s);
 hipError_t rcc_launch_calib_copy(const void* src, void* dst, size_t nbytes, hipStream_t s);
 hipError_t rcc_launch_copy_x4(const void* src, void* dst, size_t nbytes, hipStream_t s);
+hipError_t rcc_launch_issue_probe(int blocks, int iters, unsigned long long* d_stamps, unsigned* d_sink, hipStream_t s);
 hipError_t rcc_launch_rodrigues(int dir, const double* d_in, int n, double* d_out, hipStream_t s);
 hipError_t rcc_launch_synth(rcc_handle* h, const rcc_synth_params* sp, const double* d_poses,
                             int nframes, int first_index, uint8_t* d_frames, hipStream_t s);
