@@ -99,11 +99,15 @@ typedef struct rcc_config {
   double D[8];
 
   /* a3 adaptive threshold (apriltag tile min/max form) */
-  int32_t thr_min_contrast; /* a tile whose 3x3-dilated max - min is below this is "flat" (127).  Default 32: apriltag's own
-                               5 (appendix B.3) turns the sensor noise of flat areas into salt and pepper */
+  int32_t thr_min_contrast; /* a tile whose 3x3-dilated max - min is below this is "flat" (127).  Default 16 (ABI 1: 32): apriltag's
+                               own 5 (appendix B.3) turns the sensor noise of flat areas into salt and pepper */
 
   /* a4 corner extraction */
-  int32_t harris_thresh;    /* accept R >= this (integer Harris response) */
+  int32_t harris_thresh;    /* accept R >= this (integer Harris response).  Default 10240 (ABI 1: 200000, which
+                               loses the board under a Gaussian blur of sigma >= 1.5 px or 60 % shading: BASELINE.md section 4).  The
+                               flat-tile skip of the threshold + corner pass is exact -- and only then taken -- while
+                               (25 * g * g >> 4)^2 < harris_thresh with g = (4 * (thr_min_contrast - 1) + 7) >> 3: (16, 10240) and
+                               (32, 200000) satisfy it; other pairs run the pass without the skip (same results, slower). */
   int32_t cand_margin;      /* candidates keep this many pixels from the image border (>= 8) */
   int32_t max_candidates;   /* per-frame capacity of the dense pass's output list */
   int32_t nms_radius;       /* list-level suppression radius (Chebyshev), pixels */
@@ -291,7 +295,7 @@ typedef struct rcc_synth_params {
    * supersampled image (the sum of the s x s integer samples of a pixel), applied before the sensor noise:
    *   blur:      separable, symmetric; blur_taps[k] = weight at distance k (k = 0..RCC_SYNTH_BLUR_TAPS-1), and
    *              blur_taps[0] + 2 * sum(blur_taps[1..]) must be 256 (or all zero: no blur); rows and columns are clamped at the
-   *              image border.  {128, 64} is the 3-tap 1-2-1 filter; rcc_synth_gaussian_taps() in abi.py fills a Gaussian.
+   *              image border.  {128, 64} is the 3-tap 1-2-1 filter; the Python mirror (abi.py, gaussian_taps) fills a Gaussian.
    *   shading:   gain(u, v) in 1/4096: lin = 4096 + trunc(4096 * (gx * X + gy * Y) / 1000), X = (2u - (w-1)) / (w-1) in [-1, 1]
    *              (shade_x_permille = gx: relative brightness change from the centre to the right edge), Y alike;
    *              vig = 4096 - trunc(4096 * vignette_permille * r2 / (1000 * R2)), r2 = (2u-(w-1))^2 + (2v-(h-1))^2, R2 its value in

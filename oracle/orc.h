@@ -51,14 +51,15 @@ int orc_harris_candidates(const int32_t* R, int w, int h, int thresh, int margin
 int orc_filter_candidates(const orc_cand* in, int n, const uint8_t* bin, int w, int h,
                           int nms_radius, int xj_check, orc_cand* out, int cap);
 int orc_xjunction_ring(const uint8_t* bin, int w, int h, int x, int y);
+int orc_xjunction_ring_grey(const uint8_t* grey, int w, int h, int x, int y, int min_contrast);
 
 /* ---- a5 sub-pixel ---- */
 void orc_corner_subpix(const uint8_t* grey, int w, int h, const orc_cand* pts, int n,
                        int win, int max_iter, double eps, double* xy_out);
 
 /* a4.3: ring test + de-duplication at the rounded refined position; keeps input order */
-int orc_validate_refined(const orc_cand* pre, int n, const double* xy, const uint8_t* bin, int w,
-                         int h, int xj_check, int dedupe_radius, orc_cand* out, double* out_xy, int cap);
+int orc_validate_refined(const orc_cand* pre, int n, const double* xy, const uint8_t* bin, const uint8_t* grey, int w,
+                         int h, int xj_check, int min_contrast, int dedupe_radius, orc_cand* out, double* out_xy, int cap);
 
 /* ---- a6 board indexing ---- */
 /* pts: kept candidates sorted by (y,x). order_out[cols*rows] receives indices into pts in
@@ -100,8 +101,10 @@ int orc_detect_frame_ex(const rcc_config* cfg, const uint8_t* frame, int frame_i
                         orc_cand* kept_out, int32_t* nkept_out);
 
 /* ---- synthetic camera ---- */
-void orc_synth_render(const rcc_config* cfg, const rcc_synth_params* sp, const double pose[6],
-                      int frame_index, uint8_t* frame_out);
+/* returns 0, -1 for malformed optics parameters (include/rcc.h: blur taps must sum to 256), -2 out of memory */
+int orc_synth_render(const rcc_config* cfg, const rcc_synth_params* sp, const double pose[6],
+                     int frame_index, uint8_t* frame_out);
+int orc_synth_optics(const rcc_synth_params* sp, int taps[RCC_SYNTH_BLUR_TAPS]);
 void orc_board_object_points(int cols, int rows, double square, double* obj /* cols*rows*3 */);
 
 #ifdef __cplusplus

@@ -126,14 +126,15 @@ void orc_corner_subpix(const uint8_t* g, int w, int h, const orc_cand* pts, int 
  * a4.3 validation of refined corners [B].  Harris maxima sit up to ~3 px off an X-junction (the
  * gradient vanishes at its centre) and one junction can raise two maxima, so validation runs on
  * the REFINED position rounded to the nearest pixel:
- *   - X-junction ring test there (orc_xjunction_ring),
+ *   - X-junction ring tests there: on the threshold map (orc_xjunction_ring) AND on the grey image against the ring's own
+ *     mid level (orc_xjunction_ring_grey),
  *   - de-duplication: drop i if another validated j lies within Chebyshev distance dedupe_radius
  *     of it and has a larger score (or an equal score and a smaller index).  Not greedy.
  * Output keeps the input order; out[k].x/.y are the rounded refined pixel, out_xy the refined
  * position.  Returns the number kept (may exceed cap; only cap are written).
  * ---------------------------------------------------------------------------------------------- */
-int orc_validate_refined(const orc_cand* pre, int n, const double* xy, const uint8_t* bin, int w,
-                         int h, int xj_check, int dedupe_radius, orc_cand* out, double* out_xy, int cap)
+int orc_validate_refined(const orc_cand* pre, int n, const double* xy, const uint8_t* bin, const uint8_t* grey, int w,
+                         int h, int xj_check, int min_contrast, int dedupe_radius, orc_cand* out, double* out_xy, int cap)
 {
   int16_t rx[GMAXPTS_V], ry[GMAXPTS_V];
   uint8_t ok[GMAXPTS_V];
@@ -142,7 +143,7 @@ int orc_validate_refined(const orc_cand* pre, int n, const double* xy, const uin
     int x = (int)floor(xy[2 * i] + 0.5), y = (int)floor(xy[2 * i + 1] + 0.5);
     rx[i] = (int16_t)x; ry[i] = (int16_t)y;
     int v = (x >= 5 && y >= 5 && x < w - 5 && y < h - 5);
-    if (v && xj_check) v = orc_xjunction_ring(bin, w, h, x, y);
+    if (v && xj_check) v = orc_xjunction_ring(bin, w, h, x, y) && orc_xjunction_ring_grey(grey, w, h, x, y, min_contrast);
     ok[i] = (uint8_t)v;
   }
   int m = 0;

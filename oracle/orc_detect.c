@@ -151,7 +151,7 @@ int orc_ctx_detect(orc_ctx* c, const uint8_t* frame, int frame_index, rcc_detect
     if (m == 0) fc->status = RCC_FRAME_NOT_FOUND;
     return m;
   }
-  int nkept = orc_validate_refined(c->pre, npre, pxy, c->bin, w, h, cfg->xj_check, 2, c->kept, xy, max_kept);
+  int nkept = orc_validate_refined(c->pre, npre, pxy, c->bin, c->grey, w, h, cfg->xj_check, cfg->thr_min_contrast, 2, c->kept, xy, max_kept);
   fc->nkept = nkept;
   if (nkept_out) *nkept_out = nkept;
   if (kept_out) memcpy(kept_out, c->kept, sizeof(orc_cand) * (size_t)nkept);
@@ -247,8 +247,8 @@ void orc_default_config(rcc_config* c)
   c->dist_model = RCC_DIST_PLUMB_BOB;
   c->undistort = 1;
   c->D[0] = -0.28; c->D[1] = 0.07; c->D[2] = 2e-4; c->D[3] = -1e-4; c->D[4] = 0.0;
-  c->thr_min_contrast = 32;
-  c->harris_thresh = 200000;
+  c->thr_min_contrast = 16;      /* (16, 10240) since round 4: include/rcc.h */
+  c->harris_thresh = 10240;
   c->cand_margin = 8;
   c->max_candidates = 2048;
   c->nms_radius = 5;

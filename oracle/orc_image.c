@@ -335,6 +335,28 @@ int orc_xjunction_ring(const uint8_t* bin, int w, int h, int x, int y)
   return tr == 4;
 }
 
+/* The same junction read off the GREY image against the ring's own mid level [B] (round 4).  The threshold map decides "flat"
+ * per 4x4 tile from a 12x12 neighbourhood: with a low min_contrast, sensor noise in a plain area turns into salt and pepper, and
+ * a ring that crosses such an area can show four transitions by accident (seen on the L-shaped outer corners of the board, which
+ * sit ON the lattice of inner corners: one such point makes the lattice stage count 49).  Against the ring's own mid level
+ * ((min + max) >> 1) noise in a plain area is far from the level: the ring must span min_contrast and show exactly four
+ * transitions too.  a4.3 asks for BOTH tests. */
+int orc_xjunction_ring_grey(const uint8_t* grey, int w, int h, int x, int y, int min_contrast)
+{
+  if (x < 5 || y < 5 || x >= w - 5 || y >= h - 5) return 0;
+  int g[16], lo = 255, hi = 0;
+  for (int k = 0; k < 16; ++k) {
+    g[k] = grey[(size_t)(y + RING16[k][1]) * w + (x + RING16[k][0])];
+    if (g[k] < lo) lo = g[k];
+    if (g[k] > hi) hi = g[k];
+  }
+  if (hi - lo < min_contrast) return 0;
+  const int mid = (lo + hi) >> 1;
+  int tr = 0;
+  for (int k = 0; k < 16; ++k) tr += ((g[k] > mid) != (g[(k + 1) & 15] > mid));
+  return tr == 4;
+}
+
 /* list-level suppression [B]: entry i survives iff no other entry j within Chebyshev distance
  * nms_radius has a larger score (or an equal score and a smaller index).  Not greedy: decided
  * against the full input list, so it is order-independent apart from the tie break.  Survivors

@@ -44,6 +44,7 @@ def _bind(so):
     L.orc_filter_candidates.restype = C.c_int
     L.orc_find_homography.restype = C.c_int
     L.orc_xjunction_ring.restype = C.c_int
+    L.orc_xjunction_ring_grey.restype = C.c_int
     return L
 
 
@@ -149,13 +150,13 @@ def filter_candidates(cands, binimg, nms_radius, xj_check, cap=256):
     return out[:min(n, cap)].copy(), n
 
 
-def validate_refined(pre, xy, binimg, xj_check=1, dedupe_radius=2, cap=256):
+def validate_refined(pre, xy, binimg, grey, xj_check=1, min_contrast=16, dedupe_radius=2, cap=256):
     h, w = binimg.shape
     pre = np.ascontiguousarray(pre)
     xy = np.ascontiguousarray(xy, np.float64)
     out = np.zeros(cap, CAND_DT)
     oxy = np.zeros((cap, 2))
-    n = lib().orc_validate_refined(_p(pre), C.c_int(len(pre)), _p(xy), _p(np.ascontiguousarray(binimg)), C.c_int(w), C.c_int(h), C.c_int(xj_check), C.c_int(dedupe_radius), _p(out), _p(oxy), C.c_int(cap))
+    n = lib().orc_validate_refined(_p(pre), C.c_int(len(pre)), _p(xy), _p(np.ascontiguousarray(binimg)), _p(np.ascontiguousarray(grey, np.uint8)), C.c_int(w), C.c_int(h), C.c_int(xj_check), C.c_int(min_contrast), C.c_int(dedupe_radius), _p(out), _p(oxy), C.c_int(cap))
     return out[:min(n, cap)].copy(), oxy[:min(n, cap)].copy(), n
 
 
@@ -264,7 +265,9 @@ def synth_render(cfg, sp, pose, frame_index):
     ch = 3 if cfg.pixfmt == abi.RCC_PIX_BGR8 else 1
     out = np.zeros((cfg.height, cfg.stride_bytes), np.uint8)
     pose = np.ascontiguousarray(pose, np.float64)
-    lib().orc_synth_render(C.byref(cfg), C.byref(sp), _p(pose), C.c_int(frame_index), _p(out))
+    rc = lib().orc_synth_render(C.byref(cfg), C.byref(sp), _p(pose), C.c_int(frame_index), _p(out))
+    if rc != 0:
+        raise ValueError("orc_synth_render: %s" % ("malformed optics parameters (blur taps must sum to 256)" if rc == -1 else "out of memory"))
     img = out[:, :cfg.width * ch]
     return img.reshape(cfg.height, cfg.width, ch) if ch == 3 else img
 

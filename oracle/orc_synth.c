@@ -10,6 +10,7 @@
  * plus hash-based approximately Gaussian noise.  Parameters as SURVEY.md section 8(d).
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include "orc.h"
 
@@ -73,82 +74,185 @@ static int undistort_norm(int model, const double* D, double xd, double yd, doub
   return 1;
 }
 
-void orc_synth_render(const rcc_config* cfg, const rcc_synth_params* sp, const double pose[6],
-                      int frame_index, uint8_t* out)
+/* class of one sample of one pixel: 0 background, 1 white, 2 black */
+typedef struct synth_scene {
+  const rcc_config* cfg; const rcc_synth_params* sp;
+  double fx, fy, cx, cy, Hi[9];
+  int ss, fid, nsx, nsy;
+  double sq, tag, pitch, fhx, fhy, hx, hy, mg;
+} synth_scene;
+
+/* the s x s samples of pixel (u, v) summed per channel: integers (class colour + tint each), exact in double */
+static void sample_pixel(const synth_scene* S, int u, int v, double acc[3])
 {
-  const int w = cfg->width, h = cfg->height;
-  const double fx = cfg->K[0], cx = cfg->K[2], fy = cfg->K[4], cy = cfg->K[5];
-  double R[9];
-  orc_rodrigues_v2m(pose, R, NULL);
-  double H[9] = { R[0], R[1], pose[3], R[3], R[4], pose[4], R[6], R[7], pose[5] };
-  double Hi[9];
-  inv3(H, Hi);
-  const int ss = sp->supersample < 1 ? 1 : sp->supersample;
-  const double sq = sp->board_square;
-  const int fid = sp->fid_grid_x > 0 && sp->fid_grid_y > 0;       /* planar grid of fiducials instead of the board */
-  const double tag = cfg->tag_size, pitch = tag * (1.0 + 0.001 * sp->fid_gap_permille);
-  const double fhx = 0.5 * (sp->fid_grid_x * pitch - (pitch - tag)) + 0.5 * tag;   /* half extent incl. half-tag quiet zone */
-  const double fhy = 0.5 * (sp->fid_grid_y * pitch - (pitch - tag)) + 0.5 * tag;
-  const int nsx = sp->board_cols + 1, nsy = sp->board_rows + 1;   /* squares */
-  const double hx = 0.5 * nsx, hy = 0.5 * nsy;                   /* half extents in squares */
-  const double mg = (double)sp->margin_squares;
+  const rcc_config* cfg = S->cfg; const rcc_synth_params* sp = S->sp;
+  const int ss = S->ss;
+  const double* Hi = S->Hi;
   /* class colours (B,G,R): slight tints so the grey conversion is exercised */
   const int base[3] = { sp->background, sp->white, sp->black };
   const int tint[3][3] = { { 10, 0, -10 }, { -8, 0, -3 }, { 4, 0, 2 } };
-  const uint64_t key = splitmix64(sp->seed + (uint64_t)frame_index);
-  const int nch = (cfg->pixfmt == RCC_PIX_BGR8) ? 3 : 1;
-  for (int v = 0; v < h; ++v)
-    for (int u = 0; u < w; ++u) {
-      double acc[3] = { 0, 0, 0 };
-      for (int sy = 0; sy < ss; ++sy)
-        for (int sx = 0; sx < ss; ++sx) {
-          double us = (double)u + ((double)sx + 0.5) / ss - 0.5;
-          double vs = (double)v + ((double)sy + 0.5) / ss - 0.5;
-          double xd = (us - cx) / fx, yd = (vs - cy) / fy, x, y;
-          int cls = 0;
-          if (undistort_norm(cfg->dist_model, cfg->D, xd, yd, &x, &y)) {
-            double q0 = Hi[0] * x + Hi[1] * y + Hi[2];
-            double q1 = Hi[3] * x + Hi[4] * y + Hi[5];
-            double q2 = Hi[6] * x + Hi[7] * y + Hi[8];
-            if (q2 > 0.0 && fid) {
-              /* metres on the tag plane, x right, y up (object frame of camera_pose.cpp:158-161) */
-              const double Xm = q0 / q2, Ym = q1 / q2;
-              if (fabs(Xm) < fhx && fabs(Ym) < fhy) {
-                cls = 1;
-                const double gx = (Xm + fhx - 0.5 * tag) / pitch, gy = (fhy - 0.5 * tag - Ym) / pitch;   /* grid coords, row 0 on top */
-                const int ti = (int)floor(gx), tj = (int)floor(gy);
-                if (ti >= 0 && tj >= 0 && ti < sp->fid_grid_x && tj < sp->fid_grid_y) {
-                  const double u = (gx - ti) * pitch / tag * 8.0, v = (gy - tj) * pitch / tag * 8.0;   /* cells */
-                  if (u < 8.0 && v < 8.0) {
-                    const int cu = (int)floor(u), cv = (int)floor(v);
-                    if (cu == 0 || cv == 0 || cu == 7 || cv == 7) cls = 2;
-                    else {
-                      const uint64_t code = cfg->family_codes[(tj * sp->fid_grid_x + ti) % cfg->family_n];
-                      cls = ((code >> (35 - ((cv - 1) * 6 + (cu - 1)))) & 1u) ? 1 : 2;
-                    }
-                  }
-                }
-              }
-            } else if (q2 > 0.0) {
-              double X = q0 / q2 / sq, Y = q1 / q2 / sq;   /* in squares, origin at the centre */
-              if (fabs(X) < hx + mg && fabs(Y) < hy + mg) {
-                cls = 1;
-                if (fabs(X) < hx && fabs(Y) < hy) {
-                  int i = (int)floor(X + hx), j = (int)floor(Y + hy);
-                  cls = ((i + j) & 1) ? 1 : 2;
+  acc[0] = acc[1] = acc[2] = 0.0;
+  for (int sy = 0; sy < ss; ++sy)
+    for (int sx = 0; sx < ss; ++sx) {
+      double us = (double)u + ((double)sx + 0.5) / ss - 0.5;
+      double vs = (double)v + ((double)sy + 0.5) / ss - 0.5;
+      double xd = (us - S->cx) / S->fx, yd = (vs - S->cy) / S->fy, x, y;
+      int cls = 0;
+      if (undistort_norm(cfg->dist_model, cfg->D, xd, yd, &x, &y)) {
+        double q0 = Hi[0] * x + Hi[1] * y + Hi[2];
+        double q1 = Hi[3] * x + Hi[4] * y + Hi[5];
+        double q2 = Hi[6] * x + Hi[7] * y + Hi[8];
+        if (q2 > 0.0 && S->fid) {
+          /* metres on the tag plane, x right, y up (object frame of camera_pose.cpp:158-161) */
+          const double Xm = q0 / q2, Ym = q1 / q2;
+          if (fabs(Xm) < S->fhx && fabs(Ym) < S->fhy) {
+            cls = 1;
+            const double gx = (Xm + S->fhx - 0.5 * S->tag) / S->pitch, gy = (S->fhy - 0.5 * S->tag - Ym) / S->pitch;   /* grid coords, row 0 on top */
+            const int ti = (int)floor(gx), tj = (int)floor(gy);
+            if (ti >= 0 && tj >= 0 && ti < sp->fid_grid_x && tj < sp->fid_grid_y) {
+              const double cu_ = (gx - ti) * S->pitch / S->tag * 8.0, cv_ = (gy - tj) * S->pitch / S->tag * 8.0;   /* cells */
+              if (cu_ < 8.0 && cv_ < 8.0) {
+                const int cu = (int)floor(cu_), cv = (int)floor(cv_);
+                if (cu == 0 || cv == 0 || cu == 7 || cv == 7) cls = 2;
+                else {
+                  const uint64_t code = cfg->family_codes[(tj * sp->fid_grid_x + ti) % cfg->family_n];
+                  cls = ((code >> (35 - ((cv - 1) * 6 + (cu - 1)))) & 1u) ? 1 : 2;
                 }
               }
             }
           }
-          for (int c = 0; c < 3; ++c) acc[c] += (double)(base[cls] + tint[cls][c]);
+        } else if (q2 > 0.0) {
+          double X = q0 / q2 / S->sq, Y = q1 / q2 / S->sq;   /* in squares, origin at the centre */
+          if (fabs(X) < S->hx + S->mg && fabs(Y) < S->hy + S->mg) {
+            cls = 1;
+            if (fabs(X) < S->hx && fabs(Y) < S->hy) {
+              int i = (int)floor(X + S->hx), j = (int)floor(Y + S->hy);
+              cls = ((i + j) & 1) ? 1 : 2;
+            }
+          }
         }
+      }
+      for (int c = 0; c < 3; ++c) acc[c] += (double)(base[cls] + tint[cls][c]);
+    }
+}
+
+/* optics of rcc_synth_params (include/rcc.h, ABI 2): 0 = all off (the ideal camera), 1 = on and well-formed, -1 = malformed taps */
+int orc_synth_optics(const rcc_synth_params* sp, int taps[RCC_SYNTH_BLUR_TAPS])
+{
+  int any = 0, sum = 0;
+  for (int k = 0; k < RCC_SYNTH_BLUR_TAPS; ++k) {
+    taps[k] = sp->blur_taps[k];
+    if (taps[k] < 0) return -1;
+    any |= taps[k] != 0;
+    sum += (k ? 2 : 1) * taps[k];
+  }
+  if (any && sum != 256) return -1;
+  if (!any) taps[0] = 256;                    /* shading without blur: the identity filter */
+  if (sp->vignette_permille < 0 || sp->vignette_permille > 1000) return -1;
+  if (abs(sp->shade_x_permille) + abs(sp->shade_y_permille) > 1000) return -1;
+  return (any || sp->shade_x_permille || sp->shade_y_permille || sp->vignette_permille) ? 1 : 0;
+}
+
+/* gain of pixel (u, v) in 1/4096 (include/rcc.h): integer arithmetic, C truncation */
+static int64_t shading_gain(const rcc_synth_params* sp, int w, int h, int u, int v)
+{
+  const int64_t X = 2 * (int64_t)u - (w - 1), Y = 2 * (int64_t)v - (h - 1);
+  const int64_t W1 = w > 1 ? w - 1 : 1, H1 = h > 1 ? h - 1 : 1;
+  const int64_t lin = 4096 + (4096 * (int64_t)sp->shade_x_permille * X) / (1000 * W1) + (4096 * (int64_t)sp->shade_y_permille * Y) / (1000 * H1);
+  const int64_t r2 = X * X + Y * Y, R2 = (int64_t)(w - 1) * (w - 1) + (int64_t)(h - 1) * (h - 1);
+  const int64_t vig = 4096 - (4096 * (int64_t)sp->vignette_permille * r2) / (1000 * (R2 > 0 ? R2 : 1));
+  return (lin * vig) >> 12;
+}
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+int orc_synth_render(const rcc_config* cfg, const rcc_synth_params* sp, const double pose[6],
+                     int frame_index, uint8_t* out)
+{
+  const int w = cfg->width, h = cfg->height;
+  synth_scene S;
+  S.cfg = cfg; S.sp = sp;
+  S.fx = cfg->K[0]; S.cx = cfg->K[2]; S.fy = cfg->K[4]; S.cy = cfg->K[5];
+  double R[9];
+  orc_rodrigues_v2m(pose, R, NULL);
+  double H[9] = { R[0], R[1], pose[3], R[3], R[4], pose[4], R[6], R[7], pose[5] };
+  inv3(H, S.Hi);
+  S.ss = sp->supersample < 1 ? 1 : sp->supersample;
+  S.sq = sp->board_square;
+  S.fid = sp->fid_grid_x > 0 && sp->fid_grid_y > 0;       /* planar grid of fiducials instead of the board */
+  S.tag = cfg->tag_size; S.pitch = S.tag * (1.0 + 0.001 * sp->fid_gap_permille);
+  S.fhx = 0.5 * (sp->fid_grid_x * S.pitch - (S.pitch - S.tag)) + 0.5 * S.tag;   /* half extent incl. half-tag quiet zone */
+  S.fhy = 0.5 * (sp->fid_grid_y * S.pitch - (S.pitch - S.tag)) + 0.5 * S.tag;
+  S.nsx = sp->board_cols + 1; S.nsy = sp->board_rows + 1;   /* squares */
+  S.hx = 0.5 * S.nsx; S.hy = 0.5 * S.nsy;                   /* half extents in squares */
+  S.mg = (double)sp->margin_squares;
+  const int ss = S.ss;
+  const uint64_t key = splitmix64(sp->seed + (uint64_t)frame_index);
+  const int nch = (cfg->pixfmt == RCC_PIX_BGR8) ? 3 : 1;
+  int taps[RCC_SYNTH_BLUR_TAPS];
+  const int optics = orc_synth_optics(sp, taps);
+  if (optics < 0) return -1;
+  if (!optics) {
+    /* the ideal camera (ABI 1): mean of the samples + noise */
+    for (int v = 0; v < h; ++v)
+      for (int u = 0; u < w; ++u) {
+        double acc[3];
+        sample_pixel(&S, u, v, acc);
+        size_t pix = (size_t)v * w + u;
+        for (int c = 0; c < nch; ++c) {
+          double val = acc[nch == 3 ? c : 1] / (double)(ss * ss);
+          val += sp->noise_sigma * hash_gauss(key, (uint64_t)pix * 3u + (uint64_t)c);
+          double rr = rint(val);
+          int iv = rr < 0.0 ? 0 : (rr > 255.0 ? 255 : (int)rr);
+          out[(size_t)v * cfg->stride_bytes + (size_t)u * nch + c] = (uint8_t)iv;
+        }
+      }
+    return 0;
+  }
+  /* optics on.  Pass 1: the supersampled sums as integers (negative sums -- a dark class colour with a negative tint -- are kept). */
+  int32_t* A = (int32_t*)malloc((size_t)w * h * 3 * sizeof(int32_t));
+  int32_t* T = (int32_t*)malloc((size_t)w * h * 3 * sizeof(int32_t));
+  if (!A || !T) { free(A); free(T); return -2; }
+  for (int v = 0; v < h; ++v)
+    for (int u = 0; u < w; ++u) {
+      double acc[3];
+      sample_pixel(&S, u, v, acc);
+      for (int c = 0; c < 3; ++c) A[((size_t)v * w + u) * 3 + c] = (int32_t)acc[c];
+    }
+  /* Pass 2: the separable filter along the rows (weights in 1/256, columns clamped at the border) ... */
+  for (int v = 0; v < h; ++v)
+    for (int u = 0; u < w; ++u) {
+      int32_t r[3] = { 0, 0, 0 };
+      for (int i = -(RCC_SYNTH_BLUR_TAPS - 1); i < RCC_SYNTH_BLUR_TAPS; ++i) {
+        const int wi = taps[i < 0 ? -i : i];
+        if (!wi) continue;
+        const int32_t* a = &A[((size_t)v * w + clampi(u + i, 0, w - 1)) * 3];
+        r[0] += wi * a[0]; r[1] += wi * a[1]; r[2] += wi * a[2];
+      }
+      int32_t* t = &T[((size_t)v * w + u) * 3];
+      t[0] = r[0]; t[1] = r[1]; t[2] = r[2];
+    }
+  /* ... then along the columns (1/256 again, rows clamped), the gain in 1/4096, one division, noise, rounding */
+  const double scale = 256.0 * 256.0 * 4096.0 * (double)(ss * ss);
+  for (int v = 0; v < h; ++v)
+    for (int u = 0; u < w; ++u) {
+      int64_t b[3] = { 0, 0, 0 };
+      for (int j = -(RCC_SYNTH_BLUR_TAPS - 1); j < RCC_SYNTH_BLUR_TAPS; ++j) {
+        const int wj = taps[j < 0 ? -j : j];
+        if (!wj) continue;
+        const int32_t* t = &T[((size_t)clampi(v + j, 0, h - 1) * w + u) * 3];
+        b[0] += (int64_t)wj * t[0]; b[1] += (int64_t)wj * t[1]; b[2] += (int64_t)wj * t[2];
+      }
+      const int64_t g = shading_gain(sp, w, h, u, v);
       size_t pix = (size_t)v * w + u;
       for (int c = 0; c < nch; ++c) {
-        double val = acc[nch == 3 ? c : 1] / (double)(ss * ss);
+        double val = (double)(b[nch == 3 ? c : 1] * g) / scale;
         val += sp->noise_sigma * hash_gauss(key, (uint64_t)pix * 3u + (uint64_t)c);
         double rr = rint(val);
         int iv = rr < 0.0 ? 0 : (rr > 255.0 ? 255 : (int)rr);
         out[(size_t)v * cfg->stride_bytes + (size_t)u * nch + c] = (uint8_t)iv;
       }
     }
+  free(A); free(T);
+  return 0;
 }

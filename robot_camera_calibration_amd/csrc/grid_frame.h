@@ -57,18 +57,22 @@ struct BinSrc {
   }
 };
 
-// The 16 ring samples are fetched in two rounds of independent loads -- all tile levels, then all grey values (always
-// in-image addresses; the grey value is simply not used where the level says "flat") -- instead of 16 dependent
-// level -> grey pairs one after the other: the ring test was 60 us of the 260 us this one-wave-per-frame kernel takes.
-__device__ __forceinline__ bool ring_ok(const BinSrc& b, int w, int h, int x, int y)
+// The 16 ring samples are fetched in rounds of independent loads -- all grey values, then all tile levels (always in-image
+// addresses) -- instead of 16 dependent level -> grey pairs one after the other.
+// a4.3 asks for the junction twice: on the threshold map (no flat sample, four transitions) AND on the grey
+// ring against its own mid level ((min + max) >> 1; the ring must span min_contrast): the second test is what keeps the
+// salt and pepper that a low min_contrast makes of sensor noise from turning an L-shaped outer corner of the board into a junction.
+__device__ __forceinline__ bool ring_ok(const BinSrc& b, int w, int h, int x, int y, int min_contrast)
 {
   if (x < 5 || y < 5 || x >= w - 5 || y >= h - 5) return false;
-  int v[16];
+  int v[16], g[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) g[k] = b.grey[(size_t)(y + c_ring16[k][1]) * w + (x + c_ring16[k][0])];
   if (!b.thr) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = b.bin[(size_t)(y + c_ring16[k][1]) * w + (x + c_ring16[k][0])];
   } else {
-    int lv[16], g[16];
+    int lv[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int xx = x + c_ring16[k][0], yy = y + c_ring16[k][1];
@@ -76,18 +80,21 @@ __device__ __forceinline__ bool ring_ok(const BinSrc& b, int w, int h, int x, in
       lv[k] = b.thr[((size_t)band * b.th + (yy >> 2)) * RCC_THR_PITCH + ((xx - band * RCC_BAND_W) >> 2)];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) g[k] = b.grey[(size_t)(y + c_ring16[k][1]) * w + (x + c_ring16[k][0])];
-#pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = (lv[k] == 255) ? 127 : (g[k] > lv[k] ? 255 : 0);
   }
-  int tr = 0;
+  int tr = 0, lo = 255, hi = 0;
   bool any127 = false;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     any127 |= (v[k] == 127);
     tr += (v[k] != v[(k + 1) & 15]);
+    lo = min(lo, g[k]); hi = max(hi, g[k]);
   }
-  return !any127 && tr == 4;
+  const int mid = (lo + hi) >> 1;
+  int trg = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) trg += ((g[k] > mid) != (g[(k + 1) & 15] > mid));
+  return !any127 && tr == 4 && (hi - lo >= min_contrast) && trg == 4;
 }
 
 #define GRID_NOPOS 0x7FFF7FFFu                    // farther than any radius from every valid position (coordinates < 16384)
@@ -182,7 +189,7 @@ __device__ __forceinline__ void validate_frame(valid_smem& sm, const int f, cons
                                                const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
                                                const uint8_t* __restrict__ thr, int nbands, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                               const double* __restrict__ pre_xy, int xj_check, int dedupe_radius,
+                                               const double* __restrict__ pre_xy, int xj_check, int min_contrast, int dedupe_radius,
                                                rcc_frame_corners* __restrict__ fc,
                                                rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out)
 {
@@ -202,7 +209,7 @@ __device__ __forceinline__ void validate_frame(valid_smem& sm, const int f, cons
     const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
     sm.score[i] = pre[(size_t)f * RCC_MAX_KEPT + i].score;
     bool v = (xi >= 5 && yi >= 5 && xi < w - 5 && yi < h - 5);
-    if (v && xj_check) v = ring_ok(b, w, h, xi, yi);
+    if (v && xj_check) v = ring_ok(b, w, h, xi, yi, min_contrast);
     sm.pos[i] = v ? ((unsigned)xi | ((unsigned)yi << 16)) : GRID_NOPOS;
   }
   __syncthreads();

@@ -72,19 +72,15 @@ struct synth_args {
   const uint64_t* codes;
 };
 
-__global__ __launch_bounds__(256) void k_synth_render(synth_args a, const double* __restrict__ hinv, uint8_t* __restrict__ frames)
+// the s x s samples of pixel (u, v) summed per channel: integers (class colour + tint each), exact in double
+__device__ __forceinline__ void sample_pixel(const synth_args& a, const double* __restrict__ Hi, int u, int v, double acc[3])
 {
-  const int u = blockIdx.x * 64 + threadIdx.x;
-  const int v = blockIdx.y * 4 + threadIdx.y;
-  const int f = blockIdx.z;
-  if (u >= a.w || v >= a.h) return;
-  const double* Hi = hinv + 9 * (size_t)f;
   const double hx = 0.5 * a.nsx, hy = 0.5 * a.nsy, mg = (double)a.margin;
   const bool fid = a.fid_gx > 0 && a.fid_gy > 0;
   const double fhx = 0.5 * (a.fid_gx * a.pitch - (a.pitch - a.tag)) + 0.5 * a.tag;
   const double fhy = 0.5 * (a.fid_gy * a.pitch - (a.pitch - a.tag)) + 0.5 * a.tag;
   const int tint[3][3] = { { 10, 0, -10 }, { -8, 0, -3 }, { 4, 0, 2 } };
-  double acc[3] = { 0, 0, 0 };
+  acc[0] = acc[1] = acc[2] = 0.0;
   for (int sy = 0; sy < a.ss; ++sy)
     for (int sx = 0; sx < a.ss; ++sx) {
       double us = (double)u + ((double)sx + 0.5) / a.ss - 0.5;
@@ -127,16 +123,114 @@ __global__ __launch_bounds__(256) void k_synth_render(synth_args a, const double
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[c] += (double)(a.base[cls] + tint[cls][c]);
     }
+}
+
+// sensor: noise, rounding, clamping of one pixel's channel values (val[c] before the noise)
+__device__ __forceinline__ void store_pixel(const synth_args& a, int f, int u, int v, const double val3[3], uint8_t* __restrict__ frames)
+{
   const uint64_t key = splitmix64(a.seed + (uint64_t)(a.first_index + f));
   const size_t pix = (size_t)v * a.w + u;
   uint8_t* dst = frames + (size_t)f * a.frame_bytes + (size_t)v * a.stride + (size_t)u * a.nch;
   for (int c = 0; c < a.nch; ++c) {
-    double val = acc[a.nch == 3 ? c : 1] / (double)(a.ss * a.ss);
+    double val = val3[a.nch == 3 ? c : 1];
     val += a.sigma * hash_gauss(key, (uint64_t)pix * 3u + (uint64_t)c);
     double rr = rint(val);
     int iv = rr < 0.0 ? 0 : (rr > 255.0 ? 255 : (int)rr);
     dst[c] = (uint8_t)iv;
   }
+}
+
+// the ideal camera (all optics parameters zero): mean of the samples + noise, one pass
+__global__ __launch_bounds__(256) void k_synth_render(synth_args a, const double* __restrict__ hinv, uint8_t* __restrict__ frames)
+{
+  const int u = blockIdx.x * 64 + threadIdx.x;
+  const int v = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  if (u >= a.w || v >= a.h) return;
+  double acc[3];
+  sample_pixel(a, hinv + 9 * (size_t)f, u, v, acc);
+  double val[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) val[c] = acc[c] / (double)(a.ss * a.ss);
+  store_pixel(a, f, u, v, val, frames);
+}
+
+// ---- optics (rcc_synth_params, ABI 2): the supersampled sums as integers -> separable integer blur -> integer gain -> sensor.
+// pass 1: A[f][v][u][3] = the sums
+__global__ __launch_bounds__(256) void k_synth_sums(synth_args a, const double* __restrict__ hinv, int32_t* __restrict__ A)
+{
+  const int u = blockIdx.x * 64 + threadIdx.x;
+  const int v = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  if (u >= a.w || v >= a.h) return;
+  double acc[3];
+  sample_pixel(a, hinv + 9 * (size_t)f, u, v, acc);
+  int32_t* o = A + (((size_t)f * a.h + v) * a.w + u) * 3;
+  o[0] = (int32_t)acc[0]; o[1] = (int32_t)acc[1]; o[2] = (int32_t)acc[2];
+}
+struct synth_optics {
+  int taps[RCC_SYNTH_BLUR_TAPS];
+  int shade_x, shade_y, vignette;
+};
+// pass 2: along the rows (weights in 1/256, columns clamped at the border)
+__global__ __launch_bounds__(256) void k_synth_blur_rows(int w, int h, synth_optics o, const int32_t* __restrict__ A, int32_t* __restrict__ T)
+{
+  const int u = blockIdx.x * 64 + threadIdx.x;
+  const int v = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  if (u >= w || v >= h) return;
+  const int32_t* row = A + ((size_t)f * h + v) * (size_t)w * 3;
+  int32_t r0 = 0, r1 = 0, r2 = 0;
+  for (int i = -(RCC_SYNTH_BLUR_TAPS - 1); i < RCC_SYNTH_BLUR_TAPS; ++i) {
+    const int wi = o.taps[i < 0 ? -i : i];
+    if (!wi) continue;
+    const int uu = min(max(u + i, 0), w - 1);
+    r0 += wi * row[uu * 3]; r1 += wi * row[uu * 3 + 1]; r2 += wi * row[uu * 3 + 2];
+  }
+  int32_t* t = T + (((size_t)f * h + v) * w + u) * 3;
+  t[0] = r0; t[1] = r1; t[2] = r2;
+}
+// pass 3: along the columns (1/256 again, rows clamped), the gain in 1/4096, ONE division, noise, rounding
+__global__ __launch_bounds__(256) void k_synth_finish(synth_args a, synth_optics o, const int32_t* __restrict__ T, int frame0, uint8_t* __restrict__ frames)
+{
+  const int u = blockIdx.x * 64 + threadIdx.x;
+  const int v = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  if (u >= a.w || v >= a.h) return;
+  long long b0 = 0, b1 = 0, b2 = 0;
+  for (int j = -(RCC_SYNTH_BLUR_TAPS - 1); j < RCC_SYNTH_BLUR_TAPS; ++j) {
+    const int wj = o.taps[j < 0 ? -j : j];
+    if (!wj) continue;
+    const int vv = min(max(v + j, 0), a.h - 1);
+    const int32_t* t = T + (((size_t)f * a.h + vv) * a.w + u) * 3;
+    b0 += (long long)wj * t[0]; b1 += (long long)wj * t[1]; b2 += (long long)wj * t[2];
+  }
+  const long long X = 2 * (long long)u - (a.w - 1), Y = 2 * (long long)v - (a.h - 1);
+  const long long W1 = a.w > 1 ? a.w - 1 : 1, H1 = a.h > 1 ? a.h - 1 : 1;
+  const long long lin = 4096 + (4096 * (long long)o.shade_x * X) / (1000 * W1) + (4096 * (long long)o.shade_y * Y) / (1000 * H1);
+  const long long r2 = X * X + Y * Y, R2 = (long long)(a.w - 1) * (a.w - 1) + (long long)(a.h - 1) * (a.h - 1);
+  const long long vig = 4096 - (4096 * (long long)o.vignette * r2) / (1000 * (R2 > 0 ? R2 : 1));
+  const long long g = (lin * vig) >> 12;
+  const double scale = 256.0 * 256.0 * 4096.0 * (double)(a.ss * a.ss);
+  double val[3] = { (double)(b0 * g) / scale, (double)(b1 * g) / scale, (double)(b2 * g) / scale };
+  store_pixel(a, frame0 + f, u, v, val, frames);
+}
+
+// 0 = all off (the ideal camera), 1 = on and well-formed, -1 = malformed (include/rcc.h: taps >= 0, centre + 2 x the rest = 256)
+int rcc_synth_optics(const rcc_synth_params* sp, int taps[RCC_SYNTH_BLUR_TAPS])
+{
+  int any = 0, sum = 0;
+  for (int k = 0; k < RCC_SYNTH_BLUR_TAPS; ++k) {
+    taps[k] = sp->blur_taps[k];
+    if (taps[k] < 0) return -1;
+    any |= taps[k] != 0;
+    sum += (k ? 2 : 1) * taps[k];
+  }
+  if (any && sum != 256) return -1;
+  if (!any) taps[0] = 256;                    // shading without blur: the identity filter
+  if (sp->vignette_permille < 0 || sp->vignette_permille > 1000) return -1;
+  if (abs(sp->shade_x_permille) + abs(sp->shade_y_permille) > 1000) return -1;
+  return (any || sp->shade_x_permille || sp->shade_y_permille || sp->vignette_permille) ? 1 : 0;
 }
 
 hipError_t rcc_launch_synth(rcc_handle* h, const rcc_synth_params* sp, const double* d_hinv,
@@ -162,7 +256,41 @@ hipError_t rcc_launch_synth(rcc_handle* h, const rcc_synth_params* sp, const dou
     a.fid_gx = sp->fid_grid_x; a.fid_gy = sp->fid_grid_y; a.family_n = c.family_n;
     a.tag = c.tag_size; a.pitch = c.tag_size * (1.0 + 0.001 * sp->fid_gap_permille); a.codes = h->d_family;
   }
-  dim3 grid((c.width + 63) / 64, (c.height + 3) / 4, nframes), block(64, 4);
-  hipLaunchKernelGGL(k_synth_render, grid, block, 0, s, a, d_hinv, d_frames);
-  return hipGetLastError();
+  synth_optics o;
+  const int optics = rcc_synth_optics(sp, o.taps);
+  if (optics < 0) return hipErrorInvalidValue;
+  o.shade_x = sp->shade_x_permille; o.shade_y = sp->shade_y_permille; o.vignette = sp->vignette_permille;
+  dim3 block(64, 4);
+  if (!optics) {
+    dim3 grid((c.width + 63) / 64, (c.height + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_synth_render, grid, block, 0, s, a, d_hinv, d_frames);
+    return hipGetLastError();
+  }
+  // two int32 x 3 images per frame in flight: at most ~2 GiB of scratch, the batch goes through in groups of frames
+  const size_t per_frame = (size_t)c.width * c.height * 3 * sizeof(int32_t);
+  int group = (int)(((size_t)1 << 30) / per_frame);
+  if (group < 1) group = 1;
+  if (group > nframes) group = nframes;
+  const size_t need = 2 * per_frame * (size_t)group;
+  if (need > h->synth_tmp_bytes) {
+    if (h->d_synth_tmp) (void)hipFree(h->d_synth_tmp);
+    h->d_synth_tmp = nullptr; h->synth_tmp_bytes = 0;
+    hipError_t e = hipMalloc((void**)&h->d_synth_tmp, need);
+    if (e != hipSuccess) return e;
+    h->synth_tmp_bytes = need;
+  }
+  int32_t* A = (int32_t*)h->d_synth_tmp;
+  int32_t* T = A + (size_t)group * c.width * c.height * 3;
+  for (int f0 = 0; f0 < nframes; f0 += group) {
+    const int n = (nframes - f0 < group) ? nframes - f0 : group;
+    dim3 grid((c.width + 63) / 64, (c.height + 3) / 4, n);
+    synth_args b = a;
+    b.first_index = a.first_index;      // frame f of this group is batch frame f0 + f: the sums read pose f0 + f, the sensor's key is first_index + f0 + f
+    hipLaunchKernelGGL(k_synth_sums, grid, block, 0, s, b, d_hinv + 9 * (size_t)f0, A);
+    hipLaunchKernelGGL(k_synth_blur_rows, grid, block, 0, s, c.width, c.height, o, A, T);
+    hipLaunchKernelGGL(k_synth_finish, grid, block, 0, s, b, o, T, f0, d_frames);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }

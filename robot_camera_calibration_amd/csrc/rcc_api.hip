@@ -59,8 +59,10 @@ void rcc_default_config(rcc_config* c)
   c->dist_model = RCC_DIST_PLUMB_BOB;
   c->undistort = 1;
   c->D[0] = -0.28; c->D[1] = 0.07; c->D[2] = 2e-4; c->D[3] = -1e-4; c->D[4] = 0.0;
-  c->thr_min_contrast = 32;
-  c->harris_thresh = 200000;
+  // (16, 10240): the pair keeps the flat-tile skip exact (rcc_dense_allow_skip) and finds the board under blur up to sigma 2 px and
+  // 60 % shading (profiles/r04_optics_table.json); rounds 1-3 shipped (32, 200000), tuned on razor-edged renders only
+  c->thr_min_contrast = 16;
+  c->harris_thresh = 10240;
   c->cand_margin = 8;
   c->max_candidates = 2048;
   c->nms_radius = 5;
@@ -119,7 +121,7 @@ void rcc_destroy(rcc_handle* h)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = { h->d_map, h->d_tilebox, h->d_flat, h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
                    h->d_kept, h->d_kept_xy, h->d_ref_xy, h->d_fc, h->d_det, h->d_ndet, h->d_stage, h->d_pnp_buf,
-                   h->d_board_obj, h->d_img_scratch, h->d_family, h->d_sp_tab };
+                   h->d_board_obj, h->d_img_scratch, h->d_family, h->d_sp_tab, h->d_synth_tmp };
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_det) (void)hipHostFree(h->h_det);
   if (h->h_ndet) (void)hipHostFree(h->h_ndet);
@@ -1132,7 +1134,12 @@ int rcc_synth_render_batch(rcc_handle* h, const rcc_synth_params* sp, const doub
   int r = ensure_pnp_buf(h, hinv.size() * sizeof(double));
   if (r != RCC_OK) return r;
   HIPCHK(h, hipMemcpyAsync(h->d_pnp_buf, hinv.data(), hinv.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCHK(h, rcc_launch_synth(h, sp, h->d_pnp_buf, nframes, first_frame_index, (uint8_t*)d_frames, s));
+  {
+    hipError_t e = rcc_launch_synth(h, sp, h->d_pnp_buf, nframes, first_frame_index, (uint8_t*)d_frames, s);
+    if (e == hipErrorInvalidValue) return RCC_ERR_ARG;          // malformed optics parameters (include/rcc.h)
+    if (e == hipErrorOutOfMemory) return RCC_ERR_NOMEM;
+    HIPCHK(h, e);
+  }
   HIPCHK(h, hipStreamSynchronize(s));
   return RCC_OK;
 }

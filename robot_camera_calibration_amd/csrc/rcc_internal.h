@@ -135,6 +135,8 @@ struct rcc_handle {
   rcc_subpix_params sp;
   int subpix_grid;           // rcc_set_subpix_grid: width of k_subpix's grid in tag scenes; 0 = automatic
   rcc_subpix_lane* d_sp_tab;   // 64 entries
+  void* d_synth_tmp;         // synthetic camera with optics: the integer images between its passes (grown on demand)
+  size_t synth_tmp_bytes;
   char err[256];
 };
 

@@ -84,11 +84,15 @@ def test_oracle_fiducials_against_ground_truth(oracle, refine):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("optics", [None, (1.0, 300, -200, 400), (1.5, 0, 0, 0), ("3tap", -300, 200, 300)], ids=["ideal", "g1.0_shaded", "g1.5", "3tap_shaded"])
 @REFINE_MODES
-def test_hip_fiducials_match_oracle(oracle, refine):
+def test_hip_fiducials_match_oracle(oracle, refine, optics):
+    """optics: the same through the synthetic camera's blur / illumination gradient / vignette (rcc_synth_params, ABI 2)"""
     import torch
     cfg, fam = _cfg(api.default_config, B=3, refine=refine)
     (hx, hy), centres, ids, sp = _scene(cfg)
+    if optics:
+        abi.set_optics(sp, *optics)
     det = api.Detector(cfg)
     n = 3
     poses = np.concatenate([synth.sample_poses(1, cfg, seed=200 + f, z_range=(0.9, 1.6), max_tilt_deg=40, half_extent_m=(hx, hy)) for f in range(n)])
@@ -109,7 +113,7 @@ def test_hip_fiducials_match_oracle(oracle, refine):
         assert (p["x"] == st["pre"]["x"]).all() and (p["y"] == st["pre"]["y"]).all()
         assert np.abs(lst["pre_xy"][f][:st["npre"]] - st["pre_xy"]).max() == 0.0
         mine = dets[k0:k0 + m]
-        assert m == GX * GY and len(mine) == m and (mine.frame == f).all()
+        assert (m == GX * GY or optics) and m >= GX * GY - 2 and len(mine) == m and (mine.frame == f).all()
         for k in range(m):
             a, b = mine[k], odet[k]
             assert a.id == b.id and a.hamming == b.hamming and a.ncorners == 4 and a.pnp_status == b.pnp_status

@@ -33,8 +33,10 @@ def _make(cfg_mod=None, w=640, h=480, pixfmt=abi.RCC_PIX_BGR8, B=6):
     return cfg
 
 
-def _render(torch, det, cfg, n, seed=0xC0FFEE, **kw):
+def _render(torch, det, cfg, n, seed=0xC0FFEE, optics=None, **kw):
     sp = abi.default_synth_params(seed=seed)
+    if optics:
+        abi.set_optics(sp, *optics)
     poses = synth.sample_poses(n, cfg, seed=seed, **kw)
     frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
     det.synth_render(sp, poses, frames)
@@ -104,6 +106,38 @@ def test_pipeline_bgr_undistort(torch_cuda, oracle):
     det.close()
     mx, _ = _check_batch(torch_cuda, oracle, cfg, frames, 6)
     print("max diffs", mx)
+
+
+OPTICS = [("3tap", 0, 0, 0), (0.7, 300, -200, 0), (1.0, 0, 0, 400), (1.5, 300, -200, 400), (2.0, 0, 0, 0), (2.0, -300, 200, 300), (None, 300, -200, 400)]
+
+
+@pytest.mark.parametrize("optics", OPTICS, ids=lambda o: "blur%s_shade%d_%d_%d" % o)
+def test_pipeline_non_ideal_optics(torch_cuda, oracle, optics):
+    """The camera the reference really has is a webcam (real_preprocessing/README.md:25,64-65), not a renderer with razor edges:
+    frames through the synthetic camera's optics (rcc_synth_params, ABI 2: integer blur, illumination gradient, vignette) --
+    every stage of every frame against the oracle, and with the round-4 defaults (thr_min_contrast 16, harris_thresh 10240,
+    grey-ring test in a4.3) the board is found in every one of them."""
+    n = 8
+    cfg = _make(w=1280, h=720, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch_cuda, det, cfg, n, seed=911, optics=optics)
+    det.close()
+    mx, found = _check_batch(torch_cuda, oracle, cfg, frames, n)
+    print("optics", optics, "max diffs", mx)
+
+
+@pytest.mark.parametrize("mc,ht", [(32, 200000), (5, 10240)], ids=["abi1_defaults", "apriltag_min_contrast"])
+def test_pipeline_non_ideal_optics_other_thresholds(torch_cuda, oracle, mc, ht):
+    """the same scenes under the rounds-1-3 defaults (which lose boards under blur + shading: the two sides must lose the SAME
+    ones) and under apriltag's min_white_black_diff of 5 (no flat-tile skip: the pass runs every row)"""
+    def mod(c):
+        c.thr_min_contrast, c.harris_thresh = mc, ht
+    n = 6
+    cfg = _make(mod, w=1280, h=720, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch_cuda, det, cfg, n, seed=912, optics=(1.5, 300, -200, 400))
+    det.close()
+    _check_batch(torch_cuda, oracle, cfg, frames, n, expect_found=False)
 
 
 def test_pipeline_mono_raw_distortion_in_pnp(torch_cuda, oracle):
@@ -787,7 +821,9 @@ def test_rccl_allgather_records_world1(torch_cuda):
     L.rcc_dist_destroy(h)
 
 
-@pytest.mark.parametrize("kind", ["board_bgr_plumb_bob", "board_mono_no_distortion", "tags_bgr_plumb_bob", "board_mono_fisheye"])
+@pytest.mark.parametrize("kind", ["board_bgr_plumb_bob", "board_mono_no_distortion", "tags_bgr_plumb_bob", "board_mono_fisheye",
+                                  "board_bgr_plumb_bob_optics_g1.0_shaded", "board_mono_no_distortion_optics_3tap_vignette", "tags_bgr_plumb_bob_optics_g1.5_shaded",
+                                  "board_bgr_plumb_bob_optics_shaded_only"])
 def test_synthetic_camera_matches_oracle_renderer(torch_cuda, oracle, kind):
     """N4: the generator that feeds every other test and the bench (csrc/k_synth.hip, standing where rviz_simulator's
     missing camera.h was meant to be: rviz_simulator/include/rviz_simulator/target.h:40) against the oracle's renderer
@@ -800,6 +836,12 @@ def test_synthetic_camera_matches_oracle_renderer(torch_cuda, oracle, kind):
     mono = "mono" in kind
     cfg = _make(w=w, h=h, pixfmt=abi.RCC_PIX_MONO8 if mono else abi.RCC_PIX_BGR8, B=n)
     sp = abi.default_synth_params(seed=4242)
+    # optics (rcc_synth_params, ABI 2): integer blur / gradient / vignette between the supersampled sums and the sensor noise --
+    # integers and one division of exact integers on both sides: bit-exact like the ideal camera
+    if "optics_g1.0_shaded" in kind: abi.set_optics(sp, 1.0, 300, -200, 400)
+    if "optics_3tap_vignette" in kind: abi.set_optics(sp, "3tap", 0, 0, 500)
+    if "optics_g1.5_shaded" in kind: abi.set_optics(sp, 1.5, -300, 250, 300)
+    if "optics_shaded_only" in kind: abi.set_optics(sp, None, 400, 400, 200)
     fam = None
     if "no_distortion" in kind:
         abi.set_distortion(cfg, abi.RCC_DIST_NONE, ())
@@ -836,3 +878,11 @@ def test_synthetic_camera_matches_oracle_renderer(torch_cuda, oracle, kind):
         assert worst <= bound and ndiff <= n * w * h * ch // 2000
     else:
         assert ndiff == 0, "%d pixels differ (max %d)" % (ndiff, worst)
+    if "optics" in kind:
+        # malformed optics are refused by the product as by the oracle
+        bad = abi.default_synth_params(seed=1)
+        abi.set_optics(bad, [128, 64, 1])
+        det = api.Detector(cfg)
+        with pytest.raises(api.RccError):
+            det.synth_render(bad, poses, frames)
+        det.close()

@@ -177,6 +177,53 @@ def test_xjunction_ring(oracle):
     assert ring(b2, 32, 32) == 0
 
 
+def test_xjunction_ring_grey(oracle):
+    """a4.3's second test (round 4): the grey ring against its own mid level.  Known answers, the case it exists for -- an
+    L-shaped outer corner of the board whose plain side the threshold map has turned into salt and pepper (the map's ring counts
+    four transitions by accident, the grey ring two) -- and an independent whole-array derivation on random patches"""
+    L = oracle.lib()
+    P = lambda a: a.ctypes.data_as(oracle.C.c_void_p)
+    ringg = lambda gg, x, y, mc=16: L.orc_xjunction_ring_grey(P(gg), gg.shape[1], gg.shape[0], x, y, mc)
+    ringb = lambda bb, x, y: L.orc_xjunction_ring(P(bb), bb.shape[1], bb.shape[0], x, y)
+    g = _saddle(x0=32, y0=32, ang=0.2)
+    assert ringg(g, 32, 32) == 1 and ringg(g, 3, 32) == 0
+    e = np.full((64, 64), 20, np.uint8); e[:, 32:] = 235                       # straight edge
+    assert ringg(e, 32, 32) == 0
+    flat = np.full((64, 64), 128, np.uint8); flat[30:34, 30:34] += 10           # spans 10 < 16
+    assert ringg(flat, 32, 32) == 0 and ringg(flat, 32, 32, 5) in (0, 1)
+    # the L corner: black quadrant, noisy white elsewhere (range 16: not "flat" at min_contrast 16)
+    rng = np.random.default_rng(4)
+    lc = (233 + rng.integers(-8, 9, (64, 64))).astype(np.uint8)
+    lc[32:, :32] = 22
+    found = both = 0
+    RING = np.array([[5, 0], [5, 2], [4, 4], [2, 5], [0, 5], [-2, 5], [-4, 4], [-5, 2], [-5, 0], [-5, -2], [-4, -4], [-2, -5], [0, -5], [2, -5], [4, -4], [5, -2]])
+    for seed in range(12):
+        r2 = np.random.default_rng(seed)
+        lc = (233 + r2.integers(-8, 9, (64, 64))).astype(np.uint8); lc[32:, :32] = 22
+        b = oracle.threshold_tiles(lc, 16)
+        for y in range(20, 40):
+            for x in range(24, 44):
+                touches = (lc[y + RING[:, 1], x + RING[:, 0]] < 100).any()        # the ring reaches the black square
+                fb = ringb(b, x, y) and touches
+                found += fb
+                both += fb and ringg(lc, x, y)
+    assert found > 0 and both == 0            # near the corner the map alone does get fooled; the grey ring never (a ring wholly
+                                              # inside noise that spans min_contrast is another matter: that IS the noise floor)
+    # independent derivation: np.roll on the 16 ring samples
+    ang = 2 * np.pi * np.arange(16) / 16
+    ring = np.stack([np.rint(5.0 * np.cos(ang)), np.rint(5.0 * np.sin(ang))], 1).astype(int)
+    for seed in range(60):
+        r2 = np.random.default_rng(100 + seed)
+        img = _saddle(x0=16 + r2.uniform(-1, 1), y0=16 + r2.uniform(-1, 1), ang=r2.uniform(0, 3), w=32, h=32) if seed % 2 else r2.integers(0, 256, (32, 32)).astype(np.uint8)
+        img = np.clip(img.astype(int) + r2.integers(-12, 13, img.shape), 0, 255).astype(np.uint8)
+        for (x, y) in ((16, 16), (15, 17), (10, 20)):
+            v = img[y + ring[:, 1], x + ring[:, 0]].astype(int)
+            mid = (v.min() + v.max()) // 2
+            bits = v > mid
+            exp = int(v.max() - v.min() >= 16 and (bits != np.roll(bits, -1)).sum() == 4)
+            assert ringg(img, x, y) == exp
+
+
 # ---------------------------------------------------------------- a5
 @pytest.mark.parametrize("x0,y0,ang", [(31.3, 30.6, 0.3), (32.0, 32.0, 0.0), (30.75, 33.4, 0.9), (33.49, 29.51, -0.5)])
 def test_subpix_converges_to_saddle(oracle, x0, y0, ang):
@@ -381,3 +428,66 @@ def test_pipeline_against_analytic_ground_truth(oracle):
         Rg = synth.rodrigues(poses[f][:3]) @ (np.diag([-1.0, -1, 1]) if flip else np.eye(3))
         assert np.abs(synth.rodrigues(list(det.rvec)) - Rg).max() < 5e-3 and np.abs(np.array(det.tvec[:]) - poses[f][3:]).max() < 3e-3
         assert det.rms < 0.3
+
+
+def _synth_cfg(w=160, h=120, mono=True):
+    import ctypes as C
+    cfg = abi.rcc_config()
+    # (the product's defaults without loading the HIP library: only the fields the renderer reads)
+    cfg.struct_size = C.sizeof(abi.rcc_config); cfg.abi_version = abi.RCC_ABI_VERSION
+    abi.set_geometry(cfg, w, h, abi.RCC_PIX_MONO8 if mono else abi.RCC_PIX_BGR8)
+    abi.set_distortion(cfg, abi.RCC_DIST_PLUMB_BOB, abi.PLUMB_BOB_DEFAULT)
+    cfg.board_cols, cfg.board_rows, cfg.board_square = 8, 6, 0.108
+    return cfg
+
+
+def test_synth_optics_identity_filter_is_the_ideal_camera(oracle):
+    """rcc_synth_params' optics (ABI 2): the identity filter with no shading goes through the integer two-pass path and must
+    give the ideal camera's image bit for bit (the scale factors are powers of two); malformed taps are refused"""
+    cfg = _synth_cfg(mono=False)
+    pose = synth.sample_poses(1, cfg, seed=3, z_range=(2.5, 3.5))[0]
+    sp = abi.default_synth_params(seed=99)
+    ideal = oracle.synth_render(cfg, sp, pose, 7)
+    abi.set_optics(sp, [256])
+    assert (oracle.synth_render(cfg, sp, pose, 7) == ideal).all()
+    abi.set_optics(sp, [128, 64, 1])                    # sums to 258
+    with pytest.raises(ValueError):
+        oracle.synth_render(cfg, sp, pose, 7)
+    abi.set_optics(sp, "3tap", vignette=1001)
+    with pytest.raises(ValueError):
+        oracle.synth_render(cfg, sp, pose, 7)
+    for s in (0.5, 0.7, 1.0, 1.5, 2.0, 2.3):
+        t = abi.gaussian_taps(s)
+        assert t[0] + 2 * sum(t[1:]) == 256 and all(a >= b >= 0 for a, b in zip(t, t[1:]))
+
+
+@pytest.mark.parametrize("blur,shade", [("3tap", (0, 0, 0)), (1.0, (300, -200, 0)), (1.5, (0, 0, 400)), (None, (-250, 150, 300)), (2.0, (300, -200, 400))])
+def test_synth_optics_against_independent_derivation(oracle, blur, shade):
+    """the blur / gradient / vignette of the synthetic camera against whole-array numpy (different machinery: padded arrays and
+    slices instead of clamped index loops, float division of exact integers): with one sample per pixel and no noise the ideal
+    image IS the integer image the optics work on, so the expected picture follows from it alone"""
+    cfg = _synth_cfg(176, 131)
+    pose = synth.sample_poses(1, cfg, seed=11, z_range=(2.5, 3.5))[0]
+    sp = abi.default_synth_params(seed=5, noise=0.0, supersample=1)
+    A = oracle.synth_render(cfg, sp, pose, 0).astype(np.int64)
+    abi.set_optics(sp, blur, *shade)
+    got = oracle.synth_render(cfg, sp, pose, 0)
+    taps = list(sp.blur_taps)
+    if not any(taps):
+        taps[0] = 256
+    ker = np.array(taps[:0:-1] + taps, np.int64)          # 15 symmetric weights
+    h, w = A.shape
+    P = np.pad(A, ((0, 0), (7, 7)), mode="edge")
+    rows = sum(ker[k] * P[:, k:k + w] for k in range(15))
+    P = np.pad(rows, ((7, 7), (0, 0)), mode="edge")
+    both = sum(ker[k] * P[k:k + h, :] for k in range(15))
+    u, v = np.meshgrid(np.arange(w, dtype=np.int64), np.arange(h, dtype=np.int64))
+    X, Y = 2 * u - (w - 1), 2 * v - (h - 1)
+    tdiv = lambda a, b: np.sign(a) * (np.abs(a) // b)      # C division truncates toward zero
+    lin = 4096 + tdiv(4096 * shade[0] * X, 1000 * (w - 1)) + tdiv(4096 * shade[1] * Y, 1000 * (h - 1))
+    vig = 4096 - tdiv(4096 * shade[2] * (X * X + Y * Y), 1000 * ((w - 1) ** 2 + (h - 1) ** 2))
+    gain = (lin * vig) >> 12
+    exp = np.clip(np.rint((both * gain).astype(np.float64) / (65536.0 * 4096.0)), 0, 255).astype(np.uint8)
+    assert (got == exp).all(), "%d pixels differ" % int((got != exp).sum())
+    if blur:
+        assert (got != A).sum() > 500                      # it did something: the board's edges are spread
