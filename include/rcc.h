@@ -41,7 +41,9 @@ enum {
 };
 
 /* ---- enums --------------------------------------------------------------------------------- */
-enum { RCC_PIX_MONO8 = 0, RCC_PIX_BGR8 = 1 };
+/* sensor_msgs/Image encodings "mono8", "bgr8" (what cv_camera publishes, real_preprocessing/README.md:25) and "rgb8" (ABI 2):
+ * the same luma Y = (1868 B + 9617 G + 4899 R + 8192) >> 14, with the byte order of the encoding */
+enum { RCC_PIX_MONO8 = 0, RCC_PIX_BGR8 = 1, RCC_PIX_RGB8 = 2 };
 /* distortion model of D[]: plumb-bob = (k1,k2,p1,p2,k3) as in camera_pose.cpp:39,64;
  * fisheye = (k1..k4), an extension the reference does not have. */
 enum { RCC_DIST_NONE = 0, RCC_DIST_PLUMB_BOB = 1, RCC_DIST_FISHEYE = 2 };

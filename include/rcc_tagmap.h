@@ -8,6 +8,8 @@
  *       world_T_camera block (camera_pose.cpp:83-100) and targets.yaml (camera_pose.cpp:103-129),
  *       byte for byte (std::to_string's 6 decimals, the reference's spacing).
  * Pure host code (no GPU); implemented in robot_camera_calibration_amd/host/tagmap.cpp.
+ * No exception crosses this boundary and no pointer is read unchecked: rcc_tagmap_add_frame returns -1 (map unchanged) on a NULL
+ * argument, n < 1 or memory exhaustion; the writers return 0 and write an empty string on a NULL input array or exhaustion.
  */
 #ifndef RCC_TAGMAP_H_
 #define RCC_TAGMAP_H_

@@ -31,6 +31,7 @@ typedef struct orc_cand { int16_t x, y; int32_t score; } orc_cand;
 
 /* ---- a1 / a2 ingest ---- */
 void orc_bgr_to_grey(const uint8_t* bgr, int w, int h, int stride, uint8_t* grey);
+void orc_rgb_to_grey(const uint8_t* rgb, int w, int h, int stride, uint8_t* grey);
 double orc_atan_pos(double r);
 void orc_undistort_map_q5(const double K[9], int dist_model, const double D[8], int w, int h,
                           int32_t* mapx, int32_t* mapy);

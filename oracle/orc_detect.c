@@ -62,6 +62,7 @@ static void ingest(orc_ctx* c, const uint8_t* frame)
   const int w = cfg->width, h = cfg->height;
   uint8_t* g0 = c->mapx ? c->tmp : c->grey;
   if (cfg->pixfmt == RCC_PIX_BGR8) orc_bgr_to_grey(frame, w, h, cfg->stride_bytes, g0);
+  else if (cfg->pixfmt == RCC_PIX_RGB8) orc_rgb_to_grey(frame, w, h, cfg->stride_bytes, g0);
   else for (int y = 0; y < h; ++y) memcpy(g0 + (size_t)y * w, frame + (size_t)y * cfg->stride_bytes, w);
   if (c->mapx) orc_remap_q5(c->tmp, w, h, w, c->mapx, c->mapy, c->grey);
 }

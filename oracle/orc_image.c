@@ -27,6 +27,17 @@ void orc_bgr_to_grey(const uint8_t* bgr, int w, int h, int stride, uint8_t* grey
     }
   }
 }
+/* RCC_PIX_RGB8 (sensor_msgs "rgb8"): byte 0 is red */
+void orc_rgb_to_grey(const uint8_t* rgb, int w, int h, int stride, uint8_t* grey)
+{
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* row = rgb + (size_t)y * stride;
+    for (int x = 0; x < w; ++x) {
+      int r = row[3 * x], g = row[3 * x + 1], b = row[3 * x + 2];
+      grey[(size_t)y * w + x] = (uint8_t)((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14);
+    }
+  }
+}
 
 /* ------------------------------------------------------------------------------------------------
  * atan for r >= 0 from +,-,*,/ only, so that a device restatement is bit-identical [B].
@@ -179,6 +190,8 @@ int orc_ingest(const rcc_config* cfg, const uint8_t* frame, uint8_t* grey_out)
   }
   if (cfg->pixfmt == RCC_PIX_BGR8) {
     orc_bgr_to_grey(frame, w, h, cfg->stride_bytes, grey);
+  } else if (cfg->pixfmt == RCC_PIX_RGB8) {
+    orc_rgb_to_grey(frame, w, h, cfg->stride_bytes, grey);
   } else {
     for (int y = 0; y < h; ++y) memcpy(grey + (size_t)y * w, frame + (size_t)y * cfg->stride_bytes, w);
   }

@@ -262,7 +262,7 @@ def fid_corner_class(grey, pts, min_contrast):
 
 
 def synth_render(cfg, sp, pose, frame_index):
-    ch = 3 if cfg.pixfmt == abi.RCC_PIX_BGR8 else 1
+    ch = 1 if cfg.pixfmt == abi.RCC_PIX_MONO8 else 3
     out = np.zeros((cfg.height, cfg.stride_bytes), np.uint8)
     pose = np.ascontiguousarray(pose, np.float64)
     rc = lib().orc_synth_render(C.byref(cfg), C.byref(sp), _p(pose), C.c_int(frame_index), _p(out))

@@ -188,7 +188,8 @@ int orc_synth_render(const rcc_config* cfg, const rcc_synth_params* sp, const do
   S.mg = (double)sp->margin_squares;
   const int ss = S.ss;
   const uint64_t key = splitmix64(sp->seed + (uint64_t)frame_index);
-  const int nch = (cfg->pixfmt == RCC_PIX_BGR8) ? 3 : 1;
+  const int nch = (cfg->pixfmt == RCC_PIX_MONO8) ? 1 : 3;
+  const int rgb = (cfg->pixfmt == RCC_PIX_RGB8);       /* the three values of a pixel stored in the opposite order */
   int taps[RCC_SYNTH_BLUR_TAPS];
   const int optics = orc_synth_optics(sp, taps);
   if (optics < 0) return -1;
@@ -204,7 +205,7 @@ int orc_synth_render(const rcc_config* cfg, const rcc_synth_params* sp, const do
           val += sp->noise_sigma * hash_gauss(key, (uint64_t)pix * 3u + (uint64_t)c);
           double rr = rint(val);
           int iv = rr < 0.0 ? 0 : (rr > 255.0 ? 255 : (int)rr);
-          out[(size_t)v * cfg->stride_bytes + (size_t)u * nch + c] = (uint8_t)iv;
+          out[(size_t)v * cfg->stride_bytes + (size_t)u * nch + ((rgb && nch == 3) ? 2 - c : c)] = (uint8_t)iv;
         }
       }
     return 0;
@@ -250,7 +251,7 @@ int orc_synth_render(const rcc_config* cfg, const rcc_synth_params* sp, const do
         val += sp->noise_sigma * hash_gauss(key, (uint64_t)pix * 3u + (uint64_t)c);
         double rr = rint(val);
         int iv = rr < 0.0 ? 0 : (rr > 255.0 ? 255 : (int)rr);
-        out[(size_t)v * cfg->stride_bytes + (size_t)u * nch + c] = (uint8_t)iv;
+        out[(size_t)v * cfg->stride_bytes + (size_t)u * nch + ((rgb && nch == 3) ? 2 - c : c)] = (uint8_t)iv;
       }
     }
   free(A); free(T);

@@ -11,7 +11,7 @@ RCC_ABI_VERSION = 2
 # status
 RCC_OK, RCC_ERR_ARG, RCC_ERR_UNSUPPORTED, RCC_ERR_DEVICE, RCC_ERR_CAPACITY, RCC_ERR_NOMEM, RCC_ERR_STATE = 0, -1, -2, -3, -4, -5, -6
 # enums
-RCC_PIX_MONO8, RCC_PIX_BGR8 = 0, 1
+RCC_PIX_MONO8, RCC_PIX_BGR8, RCC_PIX_RGB8 = 0, 1, 2
 RCC_DIST_NONE, RCC_DIST_PLUMB_BOB, RCC_DIST_FISHEYE = 0, 1, 2
 RCC_TARGET_CHECKERBOARD, RCC_TARGET_FIDUCIAL = 0, 1
 RCC_MEM_HOST, RCC_MEM_DEVICE = 0, 1
@@ -141,7 +141,7 @@ def set_optics(sp, blur=None, shade_x=0, shade_y=0, vignette=0):
 
 def set_geometry(cfg, width, height, pixfmt=RCC_PIX_BGR8):
     """Fill the image geometry and the SURVEY 8(d) synthetic intrinsics (fx=fy=0.9 W, centre)."""
-    ch = 3 if pixfmt == RCC_PIX_BGR8 else 1
+    ch = 1 if pixfmt == RCC_PIX_MONO8 else 3
     cfg.width, cfg.height, cfg.pixfmt = width, height, pixfmt
     cfg.stride_bytes = width * ch
     cfg.frame_bytes = width * ch * height

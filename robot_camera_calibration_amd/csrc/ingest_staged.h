@@ -106,12 +106,13 @@ __device__ __forceinline__ int rcc_grey_of(int b, int g, int r)
   return (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14;
 }
 
-template <int NCH>
+// RGB = true: RCC_PIX_RGB8 (sensor_msgs "rgb8": byte 0 is red) -- the same luma with the two outer weights exchanged
+template <int NCH, bool RGB = false>
 __device__ __forceinline__ int rcc_tap(const uint8_t* __restrict__ src, int stride, int w, int h, int ix, int iy)
 {
   if ((unsigned)ix >= (unsigned)w || (unsigned)iy >= (unsigned)h) return 0;
   const uint8_t* p = src + (size_t)iy * stride + (size_t)ix * NCH;
-  if (NCH == 3) return rcc_grey_of(p[0], p[1], p[2]);
+  if (NCH == 3) return RGB ? rcc_grey_of(p[2], p[1], p[0]) : rcc_grey_of(p[0], p[1], p[2]);
   return p[0];
 }
 
@@ -135,11 +136,12 @@ __device__ __forceinline__ int rcc_tap(const uint8_t* __restrict__ src, int stri
 // evaluated exactly with byte dot products: each weight w = 64*(w >> 6) + (w & 63), so
 //   S = (dot4(px, w >> 6) << 8) + dot4(px, 4*(w & 63)) + 32768 = 4 * (sum + 8192) < 2^24
 // and the grey value is byte 2 of S (bits 23:16 = (sum + 8192) >> 14).  17 instructions per 4 pixels.
+template <bool RGB = false>
 __device__ __forceinline__ uint32_t rcc_grey4(uint32_t d0, uint32_t d1, uint32_t d2)
 {
-  // bytes: d0 = B0 G0 R0 B1, d1 = G1 R1 B2 G2, d2 = R2 B3 G3 R3
-  const uint32_t WHI = 29u | (150u << 8) | (76u << 16);            // w >> 6 for B, G, R
-  const uint32_t WLO = 48u | (68u << 8) | (140u << 16);            // 4 * (w & 63)
+  // bytes: d0 = B0 G0 R0 B1, d1 = G1 R1 B2 G2, d2 = R2 B3 G3 R3   (RGB: R and B exchanged, and so are their weights)
+  const uint32_t WHI = RGB ? (76u | (150u << 8) | (29u << 16)) : (29u | (150u << 8) | (76u << 16));            // w >> 6 for B, G, R
+  const uint32_t WLO = RGB ? (140u | (68u << 8) | (48u << 16)) : (48u | (68u << 8) | (140u << 16));            // 4 * (w & 63)
   const uint32_t p1 = __builtin_amdgcn_alignbyte(d1, d0, 3);       // B1 G1 R1 .
   const uint32_t p2 = __builtin_amdgcn_alignbyte(d2, d1, 2);       // B2 G2 R2 .
   const uint32_t s0 = (__builtin_amdgcn_udot4(d0, WHI, 0u, false) << 8) + __builtin_amdgcn_udot4(d0, WLO, 32768u, false);
@@ -151,9 +153,10 @@ __device__ __forceinline__ uint32_t rcc_grey4(uint32_t d0, uint32_t d1, uint32_t
   return lo | hi;
 }
 
+template <bool RGB = false>
 __device__ __forceinline__ uint4 rcc_grey16(const uint4& a, const uint4& b, const uint4& d)
 {
-  return make_uint4(rcc_grey4(a.x, a.y, a.z), rcc_grey4(a.w, b.x, b.y), rcc_grey4(b.z, b.w, d.x), rcc_grey4(d.y, d.z, d.w));
+  return make_uint4(rcc_grey4<RGB>(a.x, a.y, a.z), rcc_grey4<RGB>(a.w, b.x, b.y), rcc_grey4<RGB>(b.z, b.w, d.x), rcc_grey4<RGB>(d.y, d.z, d.w));
 }
 
 #define ST_TILE_LDS (2 * (ST_ROWS * ST_PITCH + 16) + 64)   // two grey buffers + the bounding-box scratch
@@ -162,7 +165,7 @@ __device__ __forceinline__ uint4 rcc_grey16(const uint4& a, const uint4& b, cons
 // `s_flag`: one int per tile of the workgroup (a workgroup may run two tiles side by side: `half`, `nhalves`); every
 // thread of the workgroup must call this the same number of times -- the barriers inside are workgroup barriers, and
 // the "box does not fit LDS" fallback is taken by all tiles of the workgroup together.  tile < 0: no tile (idle half).
-template <int NCH>
+template <int NCH, bool RGB = false>
 __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ frames,
                                                    int64_t frame_bytes, int stride, int w, int h,
                                                    const rcc_cam& cam, uint8_t* __restrict__ grey,
@@ -240,8 +243,8 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int ix = X[j] >> 5, iy = Y[j] >> 5, fx = X[j] & 31, fy = Y[j] & 31;
-        int p00 = rcc_tap<NCH>(src, stride, w, h, ix, iy), p01 = rcc_tap<NCH>(src, stride, w, h, ix + 1, iy);
-        int p10 = rcc_tap<NCH>(src, stride, w, h, ix, iy + 1), p11 = rcc_tap<NCH>(src, stride, w, h, ix + 1, iy + 1);
+        int p00 = rcc_tap<NCH, RGB>(src, stride, w, h, ix, iy), p01 = rcc_tap<NCH, RGB>(src, stride, w, h, ix + 1, iy);
+        int p10 = rcc_tap<NCH, RGB>(src, stride, w, h, ix, iy + 1), p11 = rcc_tap<NCH, RGB>(src, stride, w, h, ix + 1, iy + 1);
         int acc = (32 - fx) * (32 - fy) * p00 + fx * (32 - fy) * p01 + (32 - fx) * fy * p10 + fx * fy * p11;
         out |= (uint32_t)((acc + 512) >> 10) << (8 * j);
       }
@@ -305,7 +308,7 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
 #pragma unroll
     for (int sl = 0; sl < ST_SLOTS; ++sl) {
       if (!slot_any[sl]) continue;
-      uint32_t g4 = (NCH == 3) ? rcc_grey4(r.q[sl].x, r.q[sl].y, r.q[sl].z) : r.q[sl].x;
+      uint32_t g4 = (NCH == 3) ? rcc_grey4<RGB>(r.q[sl].x, r.q[sl].y, r.q[sl].z) : r.q[sl].x;
       if (!uin[sl]) g4 = 0;
       *reinterpret_cast<uint32_t*>(buf + ulds[sl]) = g4;
     }

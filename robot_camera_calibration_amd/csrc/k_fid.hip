@@ -576,12 +576,15 @@ __global__ __launch_bounds__(256) void k_fid_quads(const uint8_t* __restrict__ g
         for (int p0 = 0; p0 < qn; p0 += 64) {
           const bool in = p0 + lane < qn;
           const uint32_t pr = in ? s_q[p0 + lane] : 0u;
-          const int L = (int)(pr & 63u), c = (int)(pr >> 6);
-          const int cL = c0 + wbase + L, iL = s_cidx[cL];                      // lane L of this wave is active: it queued the pair
-          const uint32_t pkL = s_pk[cL], e = s_pk[c];
-          const int xL = (int)(pkL & 0xFFFFu), yL = (int)(pkL >> 16);
           int good1 = 0;
-          const bool more = fid_edge_first(g, w, h, xL, yL, (int)(e & 0xFFFFu) - xL, (int)(e >> 16) - yL, -(int)s_dy[iL], (int)s_dx[iL], (int)s_thr[iL], good1) && in;
+          bool more = false;
+          if (in) {      // lanes beyond the queue's end take no part: slot 0 of s_cidx / s_pk may never have been written (no cross-lane operation inside)
+            const int L = (int)(pr & 63u), c = (int)(pr >> 6);
+            const int cL = c0 + wbase + L, iL = s_cidx[cL];                    // lane L of this wave is active: it queued the pair
+            const uint32_t pkL = s_pk[cL], e = s_pk[c];
+            const int xL = (int)(pkL & 0xFFFFu), yL = (int)(pkL >> 16);
+            more = fid_edge_first(g, w, h, xL, yL, (int)(e & 0xFFFFu) - xL, (int)(e >> 16) - yL, -(int)s_dy[iL], (int)s_dx[iL], (int)s_thr[iL], good1);
+          }
           const unsigned long long bal = __ballot(more);
           __builtin_amdgcn_wave_barrier();
           if (more) s_q[qm + __popcll(bal & ((1ull << lane) - 1ull))] = pr | ((uint32_t)good1 << 17);

@@ -18,7 +18,7 @@
 
 // ---- variant 0: gather ------------------------------------------------------------------------
 // block (64,4): 64 quads of 4 pixels x 4 rows; grid (ceil(w/256), ceil(h/4), ceil(nframes/fpb))
-template <int NCH>
+template <int NCH, bool RGB = false>
 __global__ __launch_bounds__(256) void k_ingest_gather(const uint8_t* __restrict__ frames,
                                                        int64_t frame_bytes, int stride, int w, int h,
                                                        rcc_cam cam, uint8_t* __restrict__ grey,
@@ -44,10 +44,10 @@ __global__ __launch_bounds__(256) void k_ingest_gather(const uint8_t* __restrict
     for (int j = 0; j < 4; ++j) {
       if (x0 + j < w) {
         int ix = X[j] >> 5, iy = Y[j] >> 5, fx = X[j] & 31, fy = Y[j] & 31;
-        int p00 = rcc_tap<NCH>(src, stride, w, h, ix, iy);
-        int p01 = rcc_tap<NCH>(src, stride, w, h, ix + 1, iy);
-        int p10 = rcc_tap<NCH>(src, stride, w, h, ix, iy + 1);
-        int p11 = rcc_tap<NCH>(src, stride, w, h, ix + 1, iy + 1);
+        int p00 = rcc_tap<NCH, RGB>(src, stride, w, h, ix, iy);
+        int p01 = rcc_tap<NCH, RGB>(src, stride, w, h, ix + 1, iy);
+        int p10 = rcc_tap<NCH, RGB>(src, stride, w, h, ix, iy + 1);
+        int p11 = rcc_tap<NCH, RGB>(src, stride, w, h, ix + 1, iy + 1);
         int acc = (32 - fx) * (32 - fy) * p00 + fx * (32 - fy) * p01 + (32 - fx) * fy * p10 + fx * fy * p11;
         out |= (uint32_t)((acc + 512) >> 10) << (8 * j);
       }
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_ingest_gather(const uint8_t* __restrict
   }
 }
 
-template <int NCH>
+template <int NCH, bool RGB = false>
 __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict__ frames,
                                                        int64_t frame_bytes, int stride, int w, int h,
                                                        rcc_cam cam, uint8_t* __restrict__ grey,
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   if (tile >= ntiles) return;                       // block-uniform
   __shared__ __attribute__((aligned(16))) uint8_t lds[ST_TILE_LDS];
   __shared__ int s_flag[2];
-  ingest_staged_body<NCH>(frames, frame_bytes, stride, w, h, cam, grey, nframes, fpb, ntx, tile, bz, threadIdx.x, lds, s_flag, 0, 1, map, tilebox);
+  ingest_staged_body<NCH, RGB>(frames, frame_bytes, stride, w, h, cam, grey, nframes, fpb, ntx, tile, bz, threadIdx.x, lds, s_flag, 0, 1, map, tilebox);
 }
 
 // The frame-invariant part of the staged pass, once per handle: map[v * w + u] = Q5 source coordinates of destination
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void k_ingest_map(int w, int h, rcc_cam cam, i
 
 // ---- no undistortion: pure streaming conversion -----------------------------------------------
 // one thread per 16-pixel chunk: 3 x 16 B loads -> 1 x 16 B store
+template <bool RGB>
 __global__ __launch_bounds__(256) void k_grey_bgr_stream(const uint8_t* __restrict__ frames,
                                                          int64_t frame_bytes, int stride, int w, int h,
                                                          uint8_t* __restrict__ grey, int nframes, int aligned)
@@ -133,10 +134,10 @@ __global__ __launch_bounds__(256) void k_grey_bgr_stream(const uint8_t* __restri
     if (aligned && c * 16 + 16 <= w) {
       const uint4* s4 = reinterpret_cast<const uint4*>(src);
       uint4 a = s4[0], b = s4[1], d = s4[2];
-      *reinterpret_cast<uint4*>(dst) = rcc_grey16(a, b, d);
+      *reinterpret_cast<uint4*>(dst) = rcc_grey16<RGB>(a, b, d);
     } else {
       int n = min(16, w - c * 16);
-      for (int j = 0; j < n; ++j) dst[j] = (uint8_t)rcc_grey_of(src[3 * j], src[3 * j + 1], src[3 * j + 2]);
+      for (int j = 0; j < n; ++j) dst[j] = (uint8_t)rcc_grey_of(src[3 * j + (RGB ? 2 : 0)], src[3 * j + 1], src[3 * j + (RGB ? 0 : 2)]);
     }
   }
 }
@@ -227,7 +228,7 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
   const int w = c.width, ht = c.height;
   if (nframes <= 0) return hipSuccess;
   if (!h->undist) {
-    if (c.pixfmt == RCC_PIX_BGR8) {
+    if (c.pixfmt != RCC_PIX_MONO8) {
       int aligned = ((c.stride_bytes & 15) == 0) && ((c.frame_bytes & 15) == 0) && ((w & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0) && ((reinterpret_cast<uintptr_t>(d_grey) & 15) == 0);
       int64_t total = (int64_t)nframes * ht * ((w + 15) >> 4);
@@ -235,7 +236,10 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
       // loads in flight as the device holds waves: 1.72 -> 1.44 ms per 1024 x 1080p, the rate of the bare byte movement
       // (scratch/membench4.hip); it ran as 4096 blocks of a grid-stride loop before
       int blocks = (int)(((total + 255) / 256) < 0x7FFFFFFF ? ((total + 255) / 256) : 0x7FFFFFFF);
-      hipLaunchKernelGGL(k_grey_bgr_stream, dim3(blocks), dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, d_grey, nframes, aligned);
+      if (c.pixfmt == RCC_PIX_RGB8)
+        hipLaunchKernelGGL(k_grey_bgr_stream<true>, dim3(blocks), dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, d_grey, nframes, aligned);
+      else
+        hipLaunchKernelGGL(k_grey_bgr_stream<false>, dim3(blocks), dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, d_grey, nframes, aligned);
     } else {
       int aligned = ((c.stride_bytes & 15) == 0) && ((c.frame_bytes & 15) == 0) && ((w & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0) && ((reinterpret_cast<uintptr_t>(d_grey) & 15) == 0);
@@ -252,7 +256,10 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
     if (e != hipSuccess) return e;
     if (staged) {
       dim3 grid(8 * p.per_xcd * p.ngroups);
-      if (c.pixfmt == RCC_PIX_BGR8)
+      if (c.pixfmt == RCC_PIX_RGB8)
+        hipLaunchKernelGGL((k_ingest_staged<3, true>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, p.cam, d_grey, nframes, p.fpb, p.ntx, p.tiles, p.per_xcd,
+                           (const int2*)p.map, (const int4*)p.tilebox);
+      else if (c.pixfmt == RCC_PIX_BGR8)
         hipLaunchKernelGGL((k_ingest_staged<3>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, p.cam, d_grey, nframes, p.fpb, p.ntx, p.tiles, p.per_xcd,
                            (const int2*)p.map, (const int4*)p.tilebox);
       else
@@ -267,7 +274,9 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
   const int tiles = ((w + 255) / 256) * ((ht + 3) / 4);
   while (fpb > 1 && (int64_t)tiles * ((nframes + fpb - 1) / fpb) < 2048) fpb >>= 1;
   dim3 grid((w + 255) / 256, (ht + 3) / 4, (nframes + fpb - 1) / fpb), block(64, 4);
-  if (c.pixfmt == RCC_PIX_BGR8)
+  if (c.pixfmt == RCC_PIX_RGB8)
+    hipLaunchKernelGGL((k_ingest_gather<3, true>), grid, block, 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb);
+  else if (c.pixfmt == RCC_PIX_BGR8)
     hipLaunchKernelGGL((k_ingest_gather<3>), grid, block, 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb);
   else
     hipLaunchKernelGGL((k_ingest_gather<1>), grid, block, 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, cam, d_grey, nframes, fpb);

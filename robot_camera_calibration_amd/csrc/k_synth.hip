@@ -59,7 +59,7 @@ __device__ __forceinline__ bool undistort_norm(int model, const double* D, doubl
 }
 
 struct synth_args {
-  int w, h, stride, nch;
+  int w, h, stride, nch, rgb;      // rgb: RCC_PIX_RGB8 -- the three values of a pixel are stored in the opposite order
   int64_t frame_bytes;
   rcc_cam cam;
   int ss, nsx, nsy, margin;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void store_pixel(const synth_args& a, int f, int u, i
     val += a.sigma * hash_gauss(key, (uint64_t)pix * 3u + (uint64_t)c);
     double rr = rint(val);
     int iv = rr < 0.0 ? 0 : (rr > 255.0 ? 255 : (int)rr);
-    dst[c] = (uint8_t)iv;
+    dst[(a.rgb && a.nch == 3) ? 2 - c : c] = (uint8_t)iv;       // c counts blue, green, red
   }
 }
 
@@ -239,7 +239,8 @@ hipError_t rcc_launch_synth(rcc_handle* h, const rcc_synth_params* sp, const dou
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
   synth_args a;
-  a.w = c.width; a.h = c.height; a.stride = c.stride_bytes; a.nch = (c.pixfmt == RCC_PIX_BGR8) ? 3 : 1;
+  a.w = c.width; a.h = c.height; a.stride = c.stride_bytes; a.nch = (c.pixfmt == RCC_PIX_MONO8) ? 1 : 3;
+  a.rgb = (c.pixfmt == RCC_PIX_RGB8) ? 1 : 0;
   a.frame_bytes = c.frame_bytes;
   a.cam.fx = c.K[0]; a.cam.cx = c.K[2]; a.cam.fy = c.K[4]; a.cam.cy = c.K[5];
   for (int i = 0; i < 8; ++i) a.cam.D[i] = c.D[i];

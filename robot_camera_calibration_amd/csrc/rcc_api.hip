@@ -85,8 +85,8 @@ static int validate(const rcc_config* c)
   if (!c) return RCC_ERR_ARG;
   if (c->struct_size != sizeof(rcc_config) || c->abi_version != RCC_ABI_VERSION) return RCC_ERR_ARG;
   if (c->width < 1 || c->height < 1 || c->width > 16384 || c->height > 16384) return RCC_ERR_ARG;
-  if (c->pixfmt != RCC_PIX_MONO8 && c->pixfmt != RCC_PIX_BGR8) return RCC_ERR_ARG;
-  const int ch = c->pixfmt == RCC_PIX_BGR8 ? 3 : 1;
+  if (c->pixfmt != RCC_PIX_MONO8 && c->pixfmt != RCC_PIX_BGR8 && c->pixfmt != RCC_PIX_RGB8) return RCC_ERR_ARG;
+  const int ch = c->pixfmt == RCC_PIX_MONO8 ? 1 : 3;
   if (c->stride_bytes < c->width * ch) return RCC_ERR_ARG;
   if (c->frame_bytes < (int64_t)c->stride_bytes * c->height) return RCC_ERR_ARG;
   if (c->dist_model < RCC_DIST_NONE || c->dist_model > RCC_DIST_FISHEYE) return RCC_ERR_ARG;
@@ -542,13 +542,20 @@ static int launch_host_pipeline(rcc_handle* h, const uint8_t* host_frames, int n
   // the staging buffer and the per-frame buffers are this handle's only set: the copies wait for everything queued on s
   HIPCHK(h, hipEventRecord(h->pev[0], s));
   for (int k = 0; k < 2; ++k) HIPCHK(h, hipStreamWaitEvent(h->pstream[k], h->pev[0], 0));
-  for (int c = 0; c < nchunks; ++c) {
+  // Issue order: copy 0, then per chunk c its kernels (they wait for copy c's event) FOLLOWED by copy c + 1.  With pinned input
+  // every call returns at once and the order does not matter; with PAGEABLE input hipMemcpyAsync holds the host until the bytes
+  // have gone through the runtime's bounce buffers -- issued in this order that wait falls while the device runs chunk c's
+  // kernels, so copy and compute still overlap (all copies first, as rounds 1-3 queued them, would have serialised: no kernel
+  // launched before the last copy had finished).
+  auto issue_copy = [&](int c) -> int {
     const int f0 = c * per, f1 = (f0 + per < nframes) ? f0 + per : nframes;
     if (!h->cev[c]) HIPCHK(h, hipEventCreateWithFlags(&h->cev[c], hipEventDisableTiming));
     hipStream_t cs = h->pstream[c & 1];
     HIPCHK(h, hipMemcpyAsync(h->d_stage + (size_t)f0 * fb, host_frames + (size_t)f0 * fb, (size_t)(f1 - f0) * fb, hipMemcpyHostToDevice, cs));
     HIPCHK(h, hipEventRecord(h->cev[c], cs));
-  }
+    return RCC_OK;
+  };
+  { int rc = issue_copy(0); if (rc != RCC_OK) return rc; }
   for (int c = 0; c < nchunks; ++c) {
     const int f0 = c * per, f1 = (f0 + per < nframes) ? f0 + per : nframes;
     HIPCHK(h, hipStreamWaitEvent(s, h->cev[c], 0));
@@ -563,6 +570,7 @@ static int launch_host_pipeline(rcc_handle* h, const uint8_t* host_frames, int n
     int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, s, nullptr);
     if (r != RCC_OK) { snprintf(h->err, sizeof(h->err), "%s", v.err); return r; }
     h->bin_from_thr = v.bin_from_thr;
+    if (c + 1 < nchunks) { int rc = issue_copy(c + 1); if (rc != RCC_OK) return rc; }
   }
   for (float& m : h->last_ms) m = -1.0f;               // stages of different chunks overlap the copies: no separate durations
   return RCC_OK;

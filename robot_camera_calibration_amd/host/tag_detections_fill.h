@@ -35,6 +35,40 @@ inline void rcc_parse_family(std::istream& in, std::vector<uint64_t>& codes, int
   if (bad_lines) *bad_lines = bad;
 }
 
+// sensor_msgs/Image::encoding -> rcc_config.pixfmt, or -1 for an encoding the detector does not take.  cv_camera publishes "bgr8"
+// (real_preprocessing/README.md:25); "rgb8" and "mono8" are converted by the ingest pass itself (same luma, byte order of the
+// encoding).  Everything else -- bgra8 / rgba8 (4 bytes per pixel), yuv422, 16-bit and Bayer encodings -- is REFUSED: read as
+// BGR8 it would be mis-converted silently.  The node reports it (throttled) and skips the frame.
+inline int rcc_pixfmt_of_encoding(const std::string& enc)
+{
+  if (enc == "bgr8" || enc == "8UC3") return RCC_PIX_BGR8;
+  if (enc == "rgb8") return RCC_PIX_RGB8;
+  if (enc == "mono8" || enc == "8UC1") return RCC_PIX_MONO8;
+  return -1;
+}
+
+// Intrinsics of the detector: the rosparams camera_pose_node reads (/camera_matrix/data, 9 doubles row-major, and
+// /distortion_coefficients/data, >= 5 doubles: real_preprocessing/src/camera_pose.cpp:59-64) when both are well-formed, else the
+// K (9) and D (plumb_bob, >= 5; fewer are padded with zeros) of the last sensor_msgs/CameraInfo seen on <camera_name>/camera_info
+// (upstream pairs image + camera_info: real_preprocessing/README.md:64-65).  Returns 1 = rosparams, 2 = camera_info, 0 = neither
+// (K[0], K[4] must be positive either way).  Never throws.
+inline int rcc_pick_intrinsics(const std::vector<double>* pK, const std::vector<double>* pD,
+                               const double* infoK, const double* infoD, int ninfoD, bool have_info,
+                               double K[9], double D[5])
+{
+  if (pK && pD && pK->size() == 9 && pD->size() >= 5 && (*pK)[0] > 0.0 && (*pK)[4] > 0.0) {
+    for (int i = 0; i < 9; ++i) K[i] = (*pK)[i];
+    for (int i = 0; i < 5; ++i) D[i] = (*pD)[i];
+    return 1;
+  }
+  if (have_info && infoK && infoK[0] > 0.0 && infoK[4] > 0.0) {
+    for (int i = 0; i < 9; ++i) K[i] = infoK[i];
+    for (int i = 0; i < 5; ++i) D[i] = (infoD && i < ninfoD) ? infoD[i] : 0.0;
+    return 2;
+  }
+  return 0;
+}
+
 template <class ArrayMsg, class DetMsg, class Header>
 inline void rcc_fill_tag_detections(const rcc_detection* det, int n, const Header& header, ArrayMsg& out)
 {

@@ -10,6 +10,11 @@
 // tag_T_cam = inverse(cam_T_tag) with cam_T_tag = [Rodrigues(rvec) | tvec] (:164-172).
 // Rotation matrix -> vector for the YAML output follows cv::Rodrigues via
 // the product's own pnp_core.h.
+//
+// Boundary rules (include/rcc.h:17-18 hold here too): nothing thrown inside -- std::bad_alloc from a vector or a string --
+// crosses the C ABI: every entry point catches everything and reports failure through its return value (add_frame: -1 with the
+// map unchanged -- all storage the call can need is reserved before the first element is touched; the writers: 0 and an empty
+// string), and every pointer argument is checked before it is read.
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -106,6 +111,8 @@ static size_t emit(const std::string& s, char* buf, size_t cap) {
   return s.size();
 }
 
+static size_t emit_nothing(char* buf, size_t cap) { if (buf && cap) buf[0] = 0; return 0; }
+
 extern "C" {
 
 rcc_tagmap* rcc_tagmap_create(void) { return new (std::nothrow) rcc_tagmap(); }
@@ -113,16 +120,26 @@ void rcc_tagmap_destroy(rcc_tagmap* m) { delete m; }
 
 int rcc_tagmap_add_frame(rcc_tagmap* m, int32_t n, const int32_t* ids, const double* sizes,
                          const double* rvec, const double* tvec, double* world_T_cam, int32_t* has_pose)
-{
+try {
   if (has_pose) *has_pose = 0;
   if (!m || n < 1 || !ids || !sizes || !rvec || !tvec) return -1;     // the reference only writes non-empty files (corner_detections.cpp:43)
   Frame f;
+  f.ids.reserve(n); f.sizes.reserve(n); f.tag_T_cam.reserve(n);
   for (int i = 0; i < n; ++i) {
     f.ids.push_back(ids[i]);
     f.sizes.push_back(sizes[i]);
     f.tag_T_cam.push_back(rigid_inverse(from_rt(rvec + 3 * i, tvec + 3 * i)));   // camera_pose.cpp:172
   }
-  m->frames.push_back(f);
+  // everything the rest of the call can append is reserved now: this frame's tags plus those of every deferred frame a
+  // retry may localise.  A failed reservation throws BEFORE the map is touched; after it nothing below allocates.
+  size_t may_add = (size_t)n;
+  for (int32_t u : m->unreferenced) may_add += m->frames[u].ids.size();
+  m->frames.reserve(m->frames.size() + 1);
+  m->unreferenced.reserve(m->unreferenced.size() + 1);
+  m->ids.reserve(m->ids.size() + may_add);
+  m->sizes.reserve(m->sizes.size() + may_add);
+  m->w_T_tag.reserve(m->w_T_tag.size() + may_add);
+  m->frames.push_back(std::move(f));
   const int fn = (int)m->frames.size() - 1;
   int known = 0;
   const int status = m->reader(fn, known);                               // fileStream (:267-285)
@@ -137,6 +154,9 @@ int rcc_tagmap_add_frame(rcc_tagmap* m, int32_t n, const int32_t* ids, const dou
     if (world_T_cam) memcpy(world_T_cam, m->frames[fn].w_T_cam.v, sizeof(double) * 16);
   }
   return status;
+} catch (...) {
+  if (has_pose) *has_pose = 0;
+  return -1;
 }
 
 int rcc_tagmap_frame_pose(const rcc_tagmap* m, int32_t frame, double* world_T_cam)
@@ -158,7 +178,8 @@ int32_t rcc_tagmap_pending(const rcc_tagmap* m) { return m ? (int32_t)m->unrefer
 
 // corner_detections.cpp:18-39 (yamlDump) + the trailing "\n" of :59
 size_t rcc_yaml_detections(char* buf, size_t cap, int32_t n, const int32_t* ids, const double* sizes, const int32_t* corners)
-{
+try {
+  if (n < 0 || (n > 0 && (!ids || !sizes || !corners))) return emit_nothing(buf, cap);
   std::string s = "detections:";
   for (int i = 0; i < n; ++i) {
     s += "\n - targetID: " + std::to_string(ids[i]);
@@ -169,11 +190,14 @@ size_t rcc_yaml_detections(char* buf, size_t cap, int32_t n, const int32_t* ids,
   }
   s += "\n";
   return emit(s, buf, cap);
+} catch (...) {
+  return emit_nothing(buf, cap);
 }
 
 // camera_pose.cpp:83-100 (worldAppend)
 size_t rcc_yaml_world_T_camera(char* buf, size_t cap, const double* T)
-{
+try {
+  if (!T) return emit_nothing(buf, cap);
   M4 m; memcpy(m.v, T, sizeof(m.v));
   double r[3];
   rot_to_rvec(m, r);
@@ -181,11 +205,13 @@ size_t rcc_yaml_world_T_camera(char* buf, size_t cap, const double* T)
   s += "\n rotation: [ " + to6(r[0]) + " , " + to6(r[1]) + " , " + to6(r[2]) + " ]";
   s += "\n translation: [ " + to6(T[3]) + " , " + to6(T[7]) + " , " + to6(T[11]) + " ]";
   return emit(s, buf, cap);
+} catch (...) {
+  return emit_nothing(buf, cap);
 }
 
 // camera_pose.cpp:103-129 (targetDump)
 size_t rcc_yaml_targets(const rcc_tagmap* m, char* buf, size_t cap)
-{
+try {
   std::string s = "targets:";
   for (size_t i = 0; m && i < m->ids.size(); ++i) {
     double r[3];
@@ -203,6 +229,8 @@ size_t rcc_yaml_targets(const rcc_tagmap* m, char* buf, size_t cap)
     s += "\n    3: [ " + to6(-h) + ", " + to6(h) + ", " + std::to_string(0) + " ]";
   }
   return emit(s, buf, cap);
+} catch (...) {
+  return emit_nothing(buf, cap);
 }
 
 }  // extern "C"

@@ -37,10 +37,17 @@ while time.time() - t0 < budget:
             for i, v in enumerate(d): cfg.D[i] = float(v)
         cfg.undistort = 1 if model == abi.RCC_DIST_FISHEYE else int(rng.random() < 0.7)      # fisheye without undistortion: rcc_create refuses it (RCC_ERR_UNSUPPORTED)
         cfg.reference_mode = int(rng.random() < 0.2)
-        cfg.thr_min_contrast = int(rng.choice([5, 16, 32]))
-        desc.update(undistort=cfg.undistort, refmode=cfg.reference_mode, mc=cfg.thr_min_contrast, D=[round(cfg.D[i], 4) for i in range(5)])
+        cfg.thr_min_contrast, cfg.harris_thresh = [(5, 10240), (16, 10240), (32, 200000), (12, 3200), (16, 200000)][int(rng.integers(5))]
+        desc.update(undistort=cfg.undistort, refmode=cfg.reference_mode, mc=cfg.thr_min_contrast, ht=cfg.harris_thresh, D=[round(cfg.D[i], 4) for i in range(5)])
         sp = abi.default_synth_params(seed=seed, noise=float(rng.choice([0.0, 1.0, 2.0, 5.0])))
         lo = int(rng.integers(10, 80)); sp.black, sp.white = lo, int(rng.integers(lo + 60, 250))
+        # the camera's optics (rcc_synth_params, ABI 2): half of the configurations see blur and / or shading
+        if rng.random() < 0.5:
+            blur = [None, "3tap", 0.7, 1.0, 1.5, 2.0, float(rng.uniform(0.4, 2.3))][int(rng.integers(7))]
+            sh = (int(rng.integers(-400, 401)), int(rng.integers(-300, 301)), int(rng.integers(0, 601))) if rng.random() < 0.7 else (0, 0, 0)
+            if abs(sh[0]) + abs(sh[1]) > 1000: sh = (sh[0] // 2, sh[1] // 2, sh[2])
+            abi.set_optics(sp, blur, *sh)
+            desc.update(blur=blur, shade=sh)
         if tags:
             refine = abi.RCC_TAG_REFINE_EDGES if rng.random() < 0.6 else abi.RCC_TAG_REFINE_CORNER_SUBPIX
             abi.set_fiducial_target(cfg, abi.load_family(), tag_size=0.10); cfg.tag_refine = refine

@@ -56,3 +56,14 @@ extern "C" int shimfill_parse_family(const char* text, unsigned long long* out, 
   for (size_t i = 0; i < codes.size() && (int)i < cap; ++i) out[i] = codes[i];
   return (int)codes.size();
 }
+
+// the node's encoding policy and intrinsics fallback (tag_detections_fill.h)
+extern "C" int shimfill_pixfmt(const char* encoding) { return rcc_pixfmt_of_encoding(encoding ? std::string(encoding) : std::string()); }
+extern "C" int shimfill_pick_intrinsics(const double* pK, int npK, const double* pD, int npD, const double* infoK, const double* infoD, int ninfoD,
+                                        int have_info, double* K9, double* D5)
+{
+  std::vector<double> vK, vD;
+  if (pK) vK.assign(pK, pK + npK);
+  if (pD) vD.assign(pD, pD + npD);
+  return rcc_pick_intrinsics(pK ? &vK : nullptr, pD ? &vD : nullptr, infoK, infoD, ninfoD, have_info != 0, K9, D5);
+}

@@ -140,6 +140,31 @@ def test_pipeline_non_ideal_optics_other_thresholds(torch_cuda, oracle, mc, ht):
     _check_batch(torch_cuda, oracle, cfg, frames, n, expect_found=False)
 
 
+@pytest.mark.parametrize("w,h,undistort", [(640, 480, 1), (640, 480, 0), (645, 483, 1), (645, 483, 0)], ids=["staged", "stream", "gather", "stream_ragged"])
+def test_pipeline_rgb8(torch_cuda, oracle, w, h, undistort):
+    """RCC_PIX_RGB8 (sensor_msgs "rgb8", ABI 2): the same luma with the byte order of the encoding, through every form of the
+    ingest pass (LDS-staged tiles, streaming conversion, gather) -- every stage against the oracle, and the grey image equal to
+    that of the same scene delivered as BGR8"""
+    torch = torch_cuda
+    n = 3
+    def mod(c):
+        c.undistort = undistort
+    greys = {}
+    for fmt in (abi.RCC_PIX_RGB8, abi.RCC_PIX_BGR8):
+        cfg = _make(mod, w=w, h=h, pixfmt=fmt, B=n)
+        det = api.Detector(cfg)
+        frames, _ = _render(torch, det, cfg, n, seed=77)
+        det.detect(frames, n)
+        greys[fmt] = det.fetch_images(n)["grey"]
+        det.close()
+        if fmt == abi.RCC_PIX_RGB8:
+            rgb = frames.cpu().numpy().reshape(n, h, w, 3)
+            _check_batch(torch, oracle, cfg, frames, n, expect_found=False)
+        else:
+            assert (frames.cpu().numpy().reshape(n, h, w, 3)[..., ::-1] == rgb).all()      # the renderer wrote the same values, red first
+    assert (greys[abi.RCC_PIX_RGB8] == greys[abi.RCC_PIX_BGR8]).all()
+
+
 def test_pipeline_mono_raw_distortion_in_pnp(torch_cuda, oracle):
     """undistort = 0: detector on the raw image, PnP with D -- the reference's own arrangement
     (camera_pose.cpp:163 passes kdistCoeffs)"""
@@ -642,7 +667,14 @@ def test_host_input_pipeline_identical(torch_cuda):
         det.submit(host, n, want_corners=True); det.submit(host, n, want_corners=True)
         outs.append(det.collect()); outs.append(det.collect())
     det.set_host_chunk(0)
-    outs.append(det.detect(host.numpy(), n))                 # pageable numpy memory takes the same path
+    outs.append(det.detect(host.numpy(), n))                 # a numpy VIEW of the pinned tensor
+    pageable = np.array(host.numpy(), copy=True)             # truly pageable memory (its own malloc'ed buffer): hipMemcpyAsync then
+    for per in (0, 13):                                      # holds the host per chunk; kernels of chunk c are queued before copy c + 1
+        det.set_host_chunk(per)
+        outs.append(det.detect(pageable, n))
+        det.submit(pageable, n, want_corners=True)
+        outs.append(det.collect())
+    det.set_host_chunk(0)
     # a host-resident batch submitted while a device-resident one is in flight, on a handle that has not staged anything yet
     det2 = api.Detector(cfg)
     det2.submit(frames, n, want_corners=True)

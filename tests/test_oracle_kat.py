@@ -27,6 +27,23 @@ def test_grey_formula(oracle):
     assert list(g) == exp == [29, 150, 76, 255, 142]
 
 
+def test_grey_rgb8_is_the_same_luma(oracle):
+    """RCC_PIX_RGB8 (ABI 2): byte 0 is red -- the grey image of an RGB frame equals that of the same frame delivered as BGR"""
+    rng = np.random.default_rng(8)
+    cfg = oracle.default_config()
+    abi.set_geometry(cfg, 40, 24, abi.RCC_PIX_BGR8)
+    cfg.undistort = 0
+    bgr = rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)
+    g0 = oracle.bgr_to_grey(bgr)
+    cfg.pixfmt = abi.RCC_PIX_RGB8
+    ctx = oracle.Context(cfg)
+    _, _, _, st = ctx.detect(np.ascontiguousarray(bgr[..., ::-1]).reshape(-1), 0, stages=True)
+    ctx.close()
+    assert (st["grey"] == g0).all()
+    b, g, r = (bgr[..., k].astype(np.int64) for k in range(3))
+    assert (g0 == ((1868 * b + 9617 * g + 4899 * r + 8192) >> 14)).all()
+
+
 def test_atan_from_basic_ops(oracle):
     rs = np.concatenate([np.linspace(0, 1, 401), np.linspace(1, 50, 401), [1e-12, 0.41421356, 0.41421357, 1e6]])
     err = max(abs(oracle.atan_pos(r) - math.atan(r)) for r in rs)
