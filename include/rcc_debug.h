@@ -25,7 +25,8 @@ extern "C" {
 
 /* ---- A/B switches between bit-identical variants (each returns the previous setting) -------------------------------- */
 /* threshold + corner pass: 0 = generic LDS tiles (any geometry), 1 = band kernel (k_dense_band.hip), 2 = strip march
- * (k_dense_fast.hip), 3 = band sweep + corner kernel on the active rows (k_dense_runs.hip), 4 = one independent wavefront
+ * (k_dense_fast.hip), 3 = band sweep + corner kernel on the active rows (k_dense_runs.hip: experiments library only -- the
+ * product library runs 1 in its place), 4 = one independent wavefront
  * per window where the binary image is kept as the compact map, the band kernel otherwise (k_dense_wave.hip);
  * -1 = automatic (4 where the geometry allows it, else 2, else 0) */
 int rcc_set_dense_variant(rcc_handle* h, int variant);
@@ -38,10 +39,6 @@ int rcc_set_dense_skip(rcc_handle* h, int on);
 int rcc_set_fuse_grid_pnp(rcc_handle* h, int on);
 /* n > 1: cut each batch into n chunks (>= 64 frames) alternating over two internal streams; default 1 (a single pass is
  * faster at every size measured on MI355X: DESIGN.md section 5).  Per-stage timings exist only for n <= 1. */
-/* k_dense_wave (the step's threshold + corner kernel) as gangs of eight windows per workgroup that meet at a barrier every
- * sync_rows tile rows (a power of two; 0 = every window on its own); segments per frame for that form (0 = default).
- * Bit-identical outputs.  Returns the previous sync_rows. */
-int rcc_set_dense_gang(rcc_handle* h, int sync_rows, int segments);
 int rcc_set_pipeline(rcc_handle* h, int nchunks);
 /* host-resident batches (RCC_MEM_HOST) go over as a pipeline of chunks, each chunk's kernels under the next chunks' copies:
  * frames per chunk (0 = automatic, about 192 MiB; < 0 = one copy of the whole batch, then the kernels -- the A/B form).
@@ -98,6 +95,12 @@ int rcc_debug_pnp_probe(rcc_handle* h, const double* obj, const double* img, int
                         const double* D, int32_t dist_model, double* out);
 
 #ifdef RCC_EXPERIMENTS
+/* measurement-only forms of the threshold + corner pass, bit-identical to the product's (tests/test_experiments_library.py runs
+ * them against librcc_hip_exp.so): dense variant 3 -- the band sweep + a corner kernel on the active rows
+ * (k_dense_runs.hip; the product library runs variant 1 in its place) -- and k_dense_wave as gangs of eight windows per
+ * workgroup that meet at a barrier every sync_rows tile rows (a power of two; 0 = every window on its own); segments per
+ * frame for that form (0 = default).  Returns the previous sync_rows. */
+int rcc_set_dense_gang(rcc_handle* h, int sync_rows, int segments);
 /* experiment (scratch/t_overlap.py): the ingest pass and the threshold+corner pass over independent buffers, back to
  * back on one stream (mode 0) or launched together on two streams (mode 1); mean milliseconds per pair. */
 int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void* d_grey_out, const void* d_grey_in,

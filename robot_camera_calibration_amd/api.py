@@ -89,8 +89,9 @@ def load_library():
     L.rcc_set_fuse_grid_pnp.restype = C.c_int
     L.rcc_set_keep_binary.argtypes = [P, C.c_int]
     L.rcc_set_keep_binary.restype = C.c_int
-    L.rcc_set_dense_gang.argtypes = [P, C.c_int, C.c_int]
-    L.rcc_set_dense_gang.restype = C.c_int
+    if hasattr(L, "rcc_set_dense_gang"):          # librcc_hip_exp.so only (include/rcc_debug.h, RCC_EXPERIMENTS)
+        L.rcc_set_dense_gang.argtypes = [P, C.c_int, C.c_int]
+        L.rcc_set_dense_gang.restype = C.c_int
     L.rcc_set_host_chunk.argtypes = [P, C.c_int]
     L.rcc_set_host_chunk.restype = C.c_int
     L.rcc_set_subpix_grid.argtypes = [P, C.c_int]
@@ -139,10 +140,12 @@ EXPORTED_SYMBOLS = (
 )
 # include/rcc_debug.h: test taps, timers, A/B switches between bit-identical variants (not part of the boundary)
 DEBUG_EXPORTED_SYMBOLS = (
-    "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_set_dense_skip", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline", "rcc_set_host_chunk", "rcc_set_dense_gang", "rcc_set_subpix_grid",
+    "rcc_set_dense_variant", "rcc_set_ingest_variant", "rcc_set_dense_skip", "rcc_set_fuse_grid_pnp", "rcc_set_pipeline", "rcc_set_host_chunk", "rcc_set_subpix_grid",
     "rcc_set_pnp_variant", "rcc_last_timings", "rcc_last_step_times", "rcc_debug_measure_clock", "rcc_last_dense_kernel", "rcc_time_dense", "rcc_time_ingest", "rcc_time_copy",
     "rcc_debug_calib_copy", "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_debug_pnp_probe",
 )
+# only in librcc_hip_exp.so (make EXPERIMENTS=1): measurement-only kernel forms and one-off experiments; never in the product library
+EXPERIMENT_ONLY_SYMBOLS = ("rcc_set_dense_gang", "rcc_debug_overlap", "rcc_set_dense_fmod", "rcc_debug_grid_trace")
 # include/rcc_dist.h (librcc_dist.so: the RCCL all-gather of the record tables for non-Python hosts)
 DIST_EXPORTED_SYMBOLS = ("rcc_dist_unique_id", "rcc_dist_create", "rcc_dist_destroy", "rcc_dist_rank", "rcc_dist_world",
                          "rcc_dist_allgather_records", "rcc_dist_last_error", "rcc_dist_last_create_error")
@@ -260,6 +263,7 @@ class Detector:
         fc = np.zeros(max(nframes, 1), FC_DT) if want_corners else None
         ndet = C.c_int32(0)
         _after_torch(stream, frames)
+        self.last_stream = stream            # the HIP stream handle this batch ran on (None: the handle's own stream)
         st = self._L.rcc_detect_batch(self._h, _ptr(frames), nframes, mem, _ptr(det), C.byref(ndet),
                                       _ptr(fc), _ptr(stream))
         self._chk(st, "rcc_detect_batch")
@@ -275,6 +279,7 @@ class Detector:
             frames = np.ascontiguousarray(frames)
         fc = np.zeros(max(nframes, 1), FC_DT) if want_corners else None
         _after_torch(stream, frames)
+        self.last_stream = stream
         self._chk(self._L.rcc_detect_batch_submit(self._h, _ptr(frames), nframes, mem, _ptr(fc), _ptr(stream)), "rcc_detect_batch_submit")
         if not hasattr(self, "_pending"):
             self._pending = []
@@ -385,6 +390,9 @@ class Detector:
         return self._L.rcc_set_pipeline(self._h, int(nchunks))
 
     def set_dense_gang(self, sync_rows, segments=0):
+        """experiments library only (RCC_LIBRARY=.../librcc_hip_exp.so): k_dense_wave as gangs of eight windows"""
+        if not hasattr(self._L, "rcc_set_dense_gang"):
+            raise RuntimeError("rcc_set_dense_gang exists only in librcc_hip_exp.so (make -C csrc EXPERIMENTS=1; RCC_LIBRARY selects it)")
         return self._L.rcc_set_dense_gang(self._h, int(sync_rows), int(segments))
 
     def set_host_chunk(self, frames_per_chunk):

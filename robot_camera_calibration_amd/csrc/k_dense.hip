@@ -212,6 +212,9 @@ hipError_t rcc_launch_dense(rcc_handle* h, const uint8_t* d_grey, int nframes, u
   hipError_t e = hipMemsetAsync(d_cand_count, 0, sizeof(int32_t) * (size_t)nframes, s);
   if (e != hipSuccess) return e;
   int variant = h->dense_variant;
+#ifndef RCC_EXPERIMENTS
+  if (variant == 3) variant = 1;      // the two-kernel form lives in librcc_hip_exp.so only (include/rcc_debug.h); same results
+#endif
   const bool band_ok = rcc_dense_band_supported(h, d_grey, d_bin), march_ok = rcc_dense_march_supported(h);
   if (variant < 0) variant = band_ok ? 4 : (march_ok ? 2 : 0);     // 4: a wavefront per window where the compact map is asked for, else the band kernel
   if ((variant == 1 || variant == 3 || variant == 4) && !band_ok) variant = march_ok ? 2 : 0;

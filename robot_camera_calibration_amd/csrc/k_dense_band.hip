@@ -100,7 +100,7 @@ static void launch_band(rcc_handle* h, const uint8_t* d_grey, int nframes, uint8
   const int fchunk = fc_env > 0 ? fc_env : (nframes >= 1024 ? 16 : nframes >= 64 ? nframes / 64 : 1);   // frames per chunk (BAND_JOB)
   const long long njobs = (long long)nbands * nseg * ((nframes + 8 * fchunk - 1) / (8 * fchunk)) * 8 * fchunk;
   const int tp = rcc_flat_tp(c.height);
-  if constexpr (SPLIT)
+  if constexpr (SPLIT)      // (instantiated only by the two-kernel form: experiments library)
     hipLaunchKernelGGL((k_dense_band<MODE, PRIO, NCH, true>), dim3((unsigned)njobs), dim3(512), 0, s, d_grey, c.width, c.height, nbands, nseg, seg_tiles,
                        nframes, c.thr_min_contrast, c.harris_thresh, c.cand_margin, c.max_candidates, allow_skip, d_out, d_cand, d_cand_count, fchunk,
                        h->d_flat, tp);
@@ -163,7 +163,8 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
   h->bin_from_thr = thr ? 1 : 0;
   // split == 2: one independent wavefront per window (k_dense_wave.hip) -- the compact-map form only
   if (split == 2 && thr && rcc_dense_wave_supported(h, d_grey)) return rcc_launch_dense_wave(h, d_grey, nframes, d_cand, d_cand_count, s);
-  if (split == 1) {
+#ifdef RCC_EXPERIMENTS
+  if (split == 1) {          // the two-kernel form (measurement only, librcc_hip_exp.so)
     const int tp = rcc_flat_tp(ht);
     const size_t need = rcc_flat_index(h->cfg.batch_capacity > nframes ? h->cfg.batch_capacity : nframes, 0, 0, nbands, tp) * sizeof(unsigned long long);
     if (need > h->flat_bytes) {
@@ -181,7 +182,6 @@ hipError_t rcc_launch_dense_band(rcc_handle* h, const uint8_t* d_grey, int nfram
     if (e != hipSuccess) return e;
     return rcc_launch_dense_runs(h, d_grey, nframes, h->d_flat, tp, d_cand, d_cand_count, s);
   }
-#ifdef RCC_EXPERIMENTS
   if (memonly) { h->dense_kernel = "k_dense_band<1, 0, 9, false>"; launch_band<1, 0, 9>(h, d_grey, nframes, d_bin, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); return hipGetLastError(); }
 #endif
   if (thr && narrow) { h->dense_kernel = "k_dense_band_occ6<2, 1, 8>"; launch_band<2, 1, 8>(h, d_grey, nframes, h->d_thr, d_cand, d_cand_count, nbands, nseg, seg_tiles, allow_skip, s); }

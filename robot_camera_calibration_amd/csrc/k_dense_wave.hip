@@ -74,9 +74,10 @@ hipError_t rcc_launch_dense_wave(rcc_handle* h, const uint8_t* d_grey, int nfram
   rcc_wave_plan wp;
   rcc_dense_wave_plan(h, nframes, &wp);
   const int nbands = wp.nbands, nwin = wp.nwin, fchunk = wp.fchunk, nseg = wp.nseg, seg_tiles = wp.seg_tiles;
+#ifdef RCC_EXPERIMENTS
   const int th = c.height >> 2;
   if (h->dense_gang_sync > 0 && nwin <= 8) {
-    // the gang form (measurement only): one workgroup of eight wavefronts per band segment
+    // the gang form (measurement only, librcc_hip_exp.so): one workgroup of eight wavefronts per band segment
     int gs = h->dense_gang_seg > 0 ? h->dense_gang_seg : nseg;
     const int gst = (th + gs - 1) / gs;
     gs = (th + gst - 1) / gst;
@@ -87,6 +88,7 @@ hipError_t rcc_launch_dense_wave(rcc_handle* h, const uint8_t* d_grey, int nfram
                        d_cand, d_cand_count, fchunk, h->dense_gang_sync - 1);
     return hipGetLastError();
   }
+#endif
   const long long njobs = wp.njobs;
   h->dense_kernel = "k_dense_wave<0, 1>";
   hipLaunchKernelGGL((k_dense_wave<WAVE_PRIO, 1>), dim3((unsigned)njobs), dim3(64), 0, s, d_grey, c.width, c.height, nbands, nwin, nseg, seg_tiles,

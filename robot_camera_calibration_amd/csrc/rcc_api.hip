@@ -277,7 +277,7 @@ static int ensure_bin(rcc_handle* h)
 // will rcc_launch_dense (with want_thr set) write d_thr instead of a full image?  (mirrors its variant choice)
 static bool detect_needs_bin(const rcc_handle* h)
 {
-  const bool band_variant = h->dense_variant < 0 || h->dense_variant == 1 || h->dense_variant == 3 || h->dense_variant == 4;
+  const bool band_variant = h->dense_variant < 0 || h->dense_variant == 1 || h->dense_variant == 3 || h->dense_variant == 4;   // (3 runs as 1 in the product library)
   return h->keep_bin || !band_variant || !rcc_dense_band_supported(h, h->d_grey, nullptr);
 }
 
@@ -288,6 +288,7 @@ int rcc_set_dense_variant(rcc_handle* h, int variant)
   h->dense_variant = variant;
   return p;
 }
+#ifdef RCC_EXPERIMENTS
 // k_dense_wave as gangs of eight windows: sync_rows = 0 off, else a power of two (tile rows between the gang's barriers);
 // segments = 0: as the single-window form
 int rcc_set_dense_gang(rcc_handle* h, int sync_rows, int segments)
@@ -298,6 +299,7 @@ int rcc_set_dense_gang(rcc_handle* h, int sync_rows, int segments)
   h->dense_gang_seg = segments;
   return p;
 }
+#endif
 int rcc_set_dense_skip(rcc_handle* h, int on)
 {
   if (!h) return RCC_ERR_ARG;

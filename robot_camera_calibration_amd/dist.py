@@ -71,8 +71,12 @@ class PoseGather:
         on_gpu = getattr(device, "type", "cpu") == "cuda"
         # two send tables: the detector fills one per result slot (submit/collect keeps two batches in flight)
         self.tables = [torch.zeros((self.nslots, REC), dtype=torch.float64, device=device) for _ in range(2 if on_gpu else 1)]
-        self.recv = torch.zeros((world * self.nslots, REC), dtype=torch.float64, device=device) if dist_module is not None else None
+        # one receive buffer per send table: the records of the batch in result slot i stay readable (gathered(i)) until the next
+        # batch of that slot is exchanged -- with one batch ahead, batch k's records survive the queued exchange of batch k + 1
+        self.recvs = [torch.zeros((world * self.nslots, REC), dtype=torch.float64, device=device) for _ in self.tables] if dist_module is not None else None
+        self.recv = self.recvs[0] if self.recvs else None           # the buffer of the LAST exchange
         self.attached = False
+        self.detector = None
         self.frame_offset = 0
         # GPU ranks, inline (default): the collective is queued on the detector's stream right behind the batch that packed the
         # table -- it runs in the gap between that batch's tail and the next batch's head (tens of microseconds for 156 KB).
@@ -88,7 +92,7 @@ class PoseGather:
     def attach(self, detector, frame_offset=0):
         """GPU ranks: let the detector pack its records into this gather's tables on the device"""
         detector.set_record_tables(self.tables[0], self.tables[-1], frame_offset)
-        self.attached, self.frame_offset = True, frame_offset
+        self.attached, self.frame_offset, self.detector = True, frame_offset, detector
 
     def exchange(self, dets, slot=0, count=True):
         """One step's exchange, whatever the rank is made of: the device table of result slot `slot` when a detector
@@ -101,14 +105,22 @@ class PoseGather:
         if self.attached:
             t = self.tables[slot if slot < len(self.tables) else 0]
             i = slot if slot < len(self.tables) else 0
+            self.recv = self.recvs[i]
             if self.inline:
                 # stream order does everything: the table is complete when the batch's kernels are, and the next batch that
-                # writes this table is queued behind the collective
+                # writes this table is queued behind the collective -- PROVIDED the detector launched that batch on the stream
+                # the collective is queued on (torch's current stream).  On its own stream the next submission could repack
+                # the table under the collective: refuse instead of racing.
                 cur = torch.cuda.current_stream(self.device)
+                used = getattr(self.detector, "last_stream", cur.cuda_stream)
+                if used != cur.cuda_stream:
+                    raise RuntimeError("PoseGather(inline=True): the detector ran on stream %r, the collective is queued on torch's current stream %r -- "
+                                       "pass stream=gather.stream to detect() / submit(), or use inline=False" % (used, cur.cuda_stream))
                 e0 = torch.cuda.Event(enable_timing=True); e0.record(cur)
                 self.dist.all_gather_into_tensor(self.recv, t)
                 e1 = torch.cuda.Event(enable_timing=True); e1.record(cur)
                 self._gather_ev.append((e0, e1))
+                self.done[i] = e1
                 return self.count() if count else -1
             if self.side is None:
                 return self.run_table(t) if count else (self.dist.all_gather_into_tensor(self.recv, t), -1)[1]
@@ -135,7 +147,7 @@ class PoseGather:
         """call before the detector is handed a batch whose records go to table `slot`: orders that batch (on the
         detector's stream = torch's current stream) behind the gather that last read the table -- a device-side wait,
         long satisfied by then"""
-        if self.side is not None and self.done[slot & 1] is not None:
+        if self.done[slot & 1] is not None and getattr(self.device, "type", "cpu") == "cuda":
             torch.cuda.current_stream(self.device).wait_event(self.done[slot & 1])
 
     @property
@@ -174,13 +186,15 @@ class PoseGather:
         t.copy_(torch.from_numpy(pack(dets, self.nframes, self.tpf, frame_offset)))
         return self.run_table(t)
 
-    def gathered(self):
-        """The gathered records (world x nslots x REC).  GPU ranks: the collective ran on the side stream, so torch's
+    def gathered(self, slot=None):
+        """The gathered records (world x nslots x REC) of the last exchange, or of the last exchange of result slot `slot`.  GPU ranks: the collective ran on the side stream, so torch's
         current stream is first made to wait for the last gather (a device-side wait) -- a reader on that stream, or a
-        .cpu() issued from it, then sees the complete buffer.  There is ONE receive buffer: it holds a batch's records
-        until the next exchange() overwrites it, so consume (or copy) it before exchanging the next batch."""
+        .cpu() issued from it, then sees the complete buffer.  One receive buffer per result slot: a batch's records stay until
+        the next batch of the SAME slot is exchanged."""
         if self.recv is None:
             return self.tables[0]
+        if slot is not None:
+            return self.recvs[slot if slot < len(self.recvs) else 0]
         if self.side is not None:
             last = getattr(self, "last_done", None)
             if last is not None:

@@ -64,6 +64,15 @@ def test_library_exports_every_declared_symbol(built):
     blob = open(api.library_path(), "rb").read()
     for var in (b"RCC_DENSE_MEMONLY", b"RCC_DENSE_NSEG", b"RCC_DENSE_FCHUNK", b"RCC_RUNS_NSEG", b"RCC_INGEST_FPB", b"RCC_PNP_SOLVER"):
         assert var not in blob, "the product library still knows the environment variable %s" % var.decode()
+    # measurement-only kernel forms (the two-kernel threshold + corner variant, the gang form of k_dense_wave) are not shipped either
+    assert set(re.findall(r"\b(rcc_[a-z0-9_]+)\s*\(", experiments)) == set(api.EXPERIMENT_ONLY_SYMBOLS)
+    assert b"k_dense_runs" not in blob and b"k_mix" not in blob
+    exp_path = os.path.join(os.path.dirname(api.library_path()), "librcc_hip_exp.so")
+    if os.path.exists(exp_path):
+        E = C.CDLL(exp_path) if "C" in globals() else __import__("ctypes").CDLL(exp_path)
+        for name in api.EXPORTED_SYMBOLS + api.DEBUG_EXPORTED_SYMBOLS + api.EXPERIMENT_ONLY_SYMBOLS:
+            assert hasattr(E, name), "librcc_hip_exp.so does not export %s" % name
+        assert b"k_dense_runs" in open(exp_path, "rb").read()
 
 
 def test_dist_library_exports_every_declared_symbol(built):

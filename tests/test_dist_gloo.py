@@ -87,6 +87,52 @@ def test_pose_gather_world2(tpf):
     assert np.array_equal(res[0][2], res[1][2])                                       # every rank sees the same table
 
 
+def _ragged_worker(rank, world, port, nframes, short_rank, short_n, q):
+    """three exchanges: a full batch, then a batch that is SHORT on one rank (the ragged end of a stream: its table's remaining
+    slots must be zero, not the previous batch's records), then a full one again"""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = rdist.PoseGather(nframes, torch.device("cpu"), world, dist, rank)
+    outs = []
+    for step in range(3):
+        n_here = short_n if (step == 1 and rank == short_rank) else nframes
+        d = _fake_dets(rank + 7 * step, n_here)
+        cnt = g.run(d, frame_offset=rank * nframes)
+        outs.append((cnt, g.gathered().numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, outs))
+
+
+def test_pose_gather_world4_ragged_last_batch():
+    """the first real 8-GPU run will be the first time more than two ranks meet: four gloo ranks, one of
+    which ends its stream with a short batch -- every rank sees every rank's records in its block, the short rank's unused slots
+    are zero in that step (no stale records of the step before), and the next full step is whole again"""
+    world, nframes, short_rank, short_n = 4, 10, 2, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_ragged_worker, args=(r, world, port, nframes, short_rank, short_n, q)) for r in range(world)]
+    for p in ps: p.start()
+    res = sorted([q.get(timeout=180) for _ in ps], key=lambda t: t[0])
+    for p in ps: p.join(30)
+    for step in range(3):
+        exp = 0
+        for r in range(world):
+            n_here = short_n if (step == 1 and r == short_rank) else nframes
+            exp += len(_fake_dets(r + 7 * step, n_here))
+        for rank, outs in res:
+            cnt, tab = outs[step]
+            assert cnt == exp and tab.shape == (world * nframes, rdist.REC)
+            for r in range(world):
+                n_here = short_n if (step == 1 and r == short_rank) else nframes
+                blk = tab[r * nframes:(r + 1) * nframes]
+                _check_block(blk, _fake_dets(r + 7 * step, n_here), nframes, 1, r * nframes)
+                assert (blk[n_here:] == 0).all()
+        assert all(np.array_equal(res[0][1][step][1], o[1][step][1]) for o in res[1:])
+
+
 def test_pack_refuses_to_truncate():
     d = _fake_dets(0, 12, tpf=3)
     with pytest.raises(ValueError):

@@ -101,8 +101,9 @@ def test_counted_wait_invariant_holds_in_the_compiled_band_kernels(listing):
     depth = int(re.search(r"#define\s+BAND_DEPTH\s+(\d+)", open(os.path.join(CSRC, "dense_band_body.h")).read()).group(1))
     want_wait = "s_waitcnt vmcnt(%d) lgkmcnt(0)" % (2 * depth - 1)
     kernels = _kernels(listing)
-    # every instantiation the launcher can pick: stage / compact forms, one-band / wide-band rings, fused and sweep-only
-    assert len(kernels) >= 8, sorted(kernels)
+    # every instantiation the product's launcher can pick: stage / compact forms x one-band / wide-band rings (the sweep-only
+    # instantiations of the two-kernel form exist in the experiments build only)
+    assert len(kernels) >= 4, sorted(kernels)
     for name, ins in kernels.items():
         bars = [i for i, t in enumerate(ins) if t.startswith("s_barrier")]
         assert len(bars) == 3, "%s: %d barriers (the loop is unrolled by three)" % (name, len(bars))
@@ -147,19 +148,26 @@ def test_guard_catches_a_broken_iteration(listing):
 
 
 # ---- the wave-per-window kernel (csrc/k_dense_wave.hip): the same counted wait, no barrier -------------------------------
-@pytest.fixture(scope="module")
-def wave_listing():
+def _wave_listing(exp):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not found")
-    out = os.path.join(CSRC, "k_dense_wave.isa.s")
+    out = os.path.join(CSRC, "k_dense_wave_exp.isa.s" if exp else "k_dense_wave.isa.s")
     deps = [os.path.join(CSRC, f) for f in ("k_dense_wave.hip", "dense_wave_body.h", "dense_band_body.h", "dense_rows.h", "rcc_internal.h")]
     if not os.path.exists(out) or max(os.path.getmtime(d) for d in deps) > os.path.getmtime(out):
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
-                               "-o", out, os.path.join(CSRC, "k_dense_wave.hip")], stderr=subprocess.DEVNULL)
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only"] +
+                              (["-DRCC_EXPERIMENTS"] if exp else []) + ["-o", out, os.path.join(CSRC, "k_dense_wave.hip")], stderr=subprocess.DEVNULL)
     return open(out).read().split("\n")
 
 
+@pytest.fixture(scope="module", params=[False, True], ids=["product", "experiments"])
+def wave_listing(request):
+    """the product build carries ONE k_dense_wave (every window on its own); the gang form is instantiated only with
+    -DRCC_EXPERIMENTS (librcc_hip_exp.so), where the same invariants are checked on both"""
+    return _wave_listing(request.param), request.param
+
+
 def test_counted_wait_invariant_holds_in_the_compiled_wave_kernel(wave_listing):
+    wave_listing, exp_build = wave_listing
     """k_dense_wave: every wave is on its own, so a staged tile row is guarded by `s_waitcnt vmcnt(2 * WAVE_DEPTH - 1)` alone.
     That needs, per unrolled iteration and on every path: the wait, then the LDS-DMA of the row WAVE_DEPTH ahead as the
     first vector-memory operation, and ONE byte store of the tile levels after the corner stages have rejoined (more
@@ -169,7 +177,7 @@ def test_counted_wait_invariant_holds_in_the_compiled_wave_kernel(wave_listing):
     want_wait = "s_waitcnt vmcnt(%d) lgkmcnt(0)" % (2 * depth - 1)
     kernels = _kernels(wave_listing, "k_dense_wave")
     assert len(kernels) >= 1
-    assert len(kernels) == 2, sorted(kernels)             # every window on its own (the product's form) + gangs of eight (rcc_set_dense_gang)
+    assert len(kernels) == (2 if exp_build else 1), sorted(kernels)   # every window on its own (the product's form) [+ gangs of eight: experiments build only]
     for name, ins in kernels.items():
         gang = re.search(r"ILi\d+ELi8EE", name) is not None
         bars = [i for i, t in enumerate(ins) if t.startswith("s_barrier")]
