@@ -284,10 +284,10 @@ def trace_summary(tr, B, world=1):
         out["device_ms_all"] = [round(v, 4) for v in d]
         out["device_idle_before_ms_all"] = [round(v, 4) for v in g]
         out["device_ms_median"] = statistics.median(d)
-        late = [v for v in g if v > 0.02]
-        out["device_idle_total_ms"] = sum(v for v in g if v > 0)
+        late = [v for v in g[1:] if v > 0.1]
+        out["device_idle_total_ms"] = sum(v for v in g[1:] if v > 0)
         out["steps_submitted_late"] = len(late)
-        out["device_what"] = "HIP events on the step's stream: device_ms = the stream reaches the batch -> its records are in pinned host memory; device_idle_before = end of the previous batch -> begin of this one (about 0 while the host keeps one batch ahead; > 0.02 ms counts as a late submission)"
+        out["device_what"] = "HIP events on the step's stream: device_ms = the stream reaches the batch -> its records are in pinned host memory; device_idle_before = end of the previous batch -> begin of this one: about 0.01 ms while the host keeps one batch ahead (plus the in-line all_gather where ranks exchange records), more where the host submitted late (> 0.1 ms is counted); entry 0 is the start of the region (barrier + synchronize lie in it) and is left out of the two sums"
     if tr.get("host_during_region"):
         out["host_during_region"] = tr["host_during_region"]
         out["host_during_region_what"] = "rank 0's submitting thread over the K steps: context switches, the cgroup's quota-throttling counters (deltas), the CPU it ran on at both ends"

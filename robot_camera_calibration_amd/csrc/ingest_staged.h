@@ -159,13 +159,18 @@ __device__ __forceinline__ uint4 rcc_grey16(const uint4& a, const uint4& b, cons
   return make_uint4(rcc_grey4<RGB>(a.x, a.y, a.z), rcc_grey4<RGB>(a.w, b.x, b.y), rcc_grey4<RGB>(b.z, b.w, d.x), rcc_grey4<RGB>(d.y, d.z, d.w));
 }
 
-#define ST_TILE_LDS (2 * (ST_ROWS * ST_PITCH + 16) + 64)   // two grey buffers + the bounding-box scratch
+#define ST_TILE_LDS (2 * (ST_ROWS * ST_PITCH + 16) + 64)   // two grey buffers + the bounding-box scratch (128 x 8 tile, 256 threads)
+// the same for a 128 x TH tile worked by 32 * TH threads (TH = 8 or 16): TH + 16 LDS rows per buffer, one bounding-box slot per wave
+#define ST_TILE_LDS_T(TH) (2 * (((TH) + 16) * ST_PITCH + 16) + 16 * ((TH) / 2))
 
-// One 128x8 destination tile by 256 threads (tid), frames [bz * fpb, ...).  `lds`: this tile's ST_TILE_LDS bytes;
+// TH = 16 (round 4): a 128 x 16 tile by 512 threads.  The source box of a tile is its destination rows plus what the lens bends
+// into them plus one row of taps: about 10 source rows for 8 destination rows, about 18-19 for 16 -- 1.16 instead of 1.25 source
+// rows loaded and converted per destination row, and half the barriers per pixel.  Same arithmetic, same bytes.
+// One 128 x TH destination tile by 32 * TH threads (tid), frames [bz * fpb, ...).  `lds`: this tile's ST_TILE_LDS bytes;
 // `s_flag`: one int per tile of the workgroup (a workgroup may run two tiles side by side: `half`, `nhalves`); every
 // thread of the workgroup must call this the same number of times -- the barriers inside are workgroup barriers, and
 // the "box does not fit LDS" fallback is taken by all tiles of the workgroup together.  tile < 0: no tile (idle half).
-template <int NCH, bool RGB = false>
+template <int NCH, bool RGB = false, int TH = ST_TH>
 __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ frames,
                                                    int64_t frame_bytes, int stride, int w, int h,
                                                    const rcc_cam& cam, uint8_t* __restrict__ grey,
@@ -173,13 +178,17 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
                                                    uint8_t* lds, int* s_flag, const int half, const int nhalves,
                                                    const int2* __restrict__ map = nullptr, const int4* __restrict__ tilebox = nullptr)
 {
+  static_assert(TH == 8 || TH == 16 || TH == 32, "tile height");
+  constexpr int NT = 32 * TH;                        // threads of the tile
+  constexpr int ROWS = TH + 16;                      // LDS rows per buffer (ST_ROWS for TH = 8)
+  constexpr int SLOTS = (TH == 8) ? ST_SLOTS : 2;    // 4-pixel source units per thread: boxes of up to 768 / 1024 units
   const int tv = tile < 0 ? 0 : tile;
   const int by = tv / ntx, bx = tv - by * ntx;
-  uint8_t (*sbuf)[ST_ROWS * ST_PITCH + 16] = reinterpret_cast<uint8_t (*)[ST_ROWS * ST_PITCH + 16]>(lds);   // two buffers; +16: dump slot of idle lanes
-  int (*s_red)[4] = reinterpret_cast<int (*)[4]>(lds + 2 * (ST_ROWS * ST_PITCH + 16));                       // [4][4]
-  const int tx = tid & 31, ty = tid >> 5;           // 32 quads x 8 rows
+  uint8_t (*sbuf)[ROWS * ST_PITCH + 16] = reinterpret_cast<uint8_t (*)[ROWS * ST_PITCH + 16]>(lds);   // two buffers; +16: dump slot of idle lanes
+  int (*s_red)[4] = reinterpret_cast<int (*)[4]>(lds + 2 * (ROWS * ST_PITCH + 16));                       // [NT / 64][4]
+  const int tx = tid & 31, ty = tid >> 5;           // 32 quads x TH rows
   const int x0 = bx * ST_TW + tx * 4;
-  const int y = by * ST_TH + ty;
+  const int y = by * TH + ty;
   const bool inside = (tile >= 0) && (y < h) && (x0 < w);          // w % 16 == 0: a quad is all in or all out
   int32_t X[4], Y[4];
   int mnx = INT32_MAX, mxx = INT32_MIN, mny = INT32_MAX, mxy = INT32_MIN;
@@ -214,10 +223,9 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
   }
   if ((tid & 63) == 0) { s_red[tid >> 6][0] = mnx; s_red[tid >> 6][1] = mxx; s_red[tid >> 6][2] = mny; s_red[tid >> 6][3] = mxy; }
   __syncthreads();
-  mnx = min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0]));
-  mxx = max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1]));
-  mny = min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2]));
-  mxy = max(max(s_red[0][3], s_red[1][3]), max(s_red[2][3], s_red[3][3]));
+  mnx = s_red[0][0]; mxx = s_red[0][1]; mny = s_red[0][2]; mxy = s_red[0][3];
+#pragma unroll
+  for (int q = 1; q < NT / 64; ++q) { mnx = min(mnx, s_red[q][0]); mxx = max(mxx, s_red[q][1]); mny = min(mny, s_red[q][2]); mxy = max(mxy, s_red[q][3]); }
   }
   const int f0 = bz * fpb;
   const int f1 = min(f0 + fpb, nframes);
@@ -229,7 +237,7 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
   const int upr = (spanx < 100000) ? (((mxx + 1) - bxa) / 4 + 1) : (1 << 20);        // units per box row
   const int bh = (spany < 100000) ? (mxy + 1 - mny + 1) : (1 << 20);
   const int by0 = mny;
-  const bool fits_here = (tile >= 0) && (upr * 4 <= ST_PITCH) && (bh <= ST_ROWS) && (upr * bh <= 256 * ST_SLOTS);   // uniform over the tile's threads
+  const bool fits_here = (tile >= 0) && (upr * 4 <= ST_PITCH) && (bh <= ROWS) && (upr * bh <= NT * SLOTS);   // uniform over the tile's threads
   if (tid == 0) s_flag[half] = fits_here ? 1 : 0;
   __syncthreads();
   const bool fits = s_flag[0] && (nhalves == 1 || s_flag[1]);      // workgroup-uniform: the barriers below need every thread
@@ -258,24 +266,26 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
   // conversion no longer sits on the one or two waves that would own whole 16-pixel groups -- the block's waves
   // reach the barrier together.
   const int nunits = upr * bh;
-  int uoff[ST_SLOTS], ulds[ST_SLOTS];
-  bool uact[ST_SLOTS], uin[ST_SLOTS];
+  int uoff[SLOTS], ulds[SLOTS];
+  bool uact[SLOTS], uin[SLOTS];
 #pragma unroll
-  for (int sl = 0; sl < ST_SLOTS; ++sl) {
-    const int u = ((tid + 64 * (tv & 3)) & 255) + 256 * sl;     // the waves that get the partly filled last slot rotate with the tile
+  for (int sl = 0; sl < SLOTS; ++sl) {
+    const int u = ((tid + 64 * (tv & 3)) & (NT - 1)) + NT * sl;     // the waves that get the partly filled last slot rotate with the tile
     const int ur = u / upr, uc = u - ur * upr;
     uact[sl] = u < nunits;
     const int sx = bxa + 4 * uc, sy = by0 + ur;
     uin[sl] = uact[sl] && sx >= 0 && sx < w && sy >= 0 && sy < h;
     uoff[sl] = min(max(sy, 0), h - 1) * stride + min(max(sx, 0), w - 4) * NCH;     // clamped: always a valid address
-    ulds[sl] = uact[sl] ? ur * ST_PITCH + 4 * uc : ST_ROWS * ST_PITCH;             // idle units write the dump slot
+    ulds[sl] = uact[sl] ? ur * ST_PITCH + 4 * uc : ROWS * ST_PITCH;             // idle units write the dump slot
   }
   // per destination pixel: LDS dword address of the tap pair, byte shift, and the bilinear weights
   // in the form the byte dot product takes them
   int taddr[4], tsh[4], wx[4], wy0[4], wy1[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int toff = ((Y[j] >> 5) - by0) * ST_PITCH + ((X[j] >> 5) - bxa);
+    // (a thread below the image -- the lower half of a 16-row tile on the last tile row of a height that is 8 mod 16 -- reads
+    // the box's first dword and stores nothing)
+    const int toff = inside ? ((Y[j] >> 5) - by0) * ST_PITCH + ((X[j] >> 5) - bxa) : 0;
     const int fx = X[j] & 31, fy = Y[j] & 31;
     taddr[j] = toff & ~3;
     tsh[j] = toff & 3;
@@ -285,20 +295,20 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
   }
 
   // Straight-line frame loop (the variant requires width % 128 == 0 and height % 8 == 0, so every
-  // thread owns 4 destination pixels): loads are unconditional within an active slot -- an out-of-image unit reads
+  // thread inside the image owns 4 destination pixels): loads are unconditional within an active slot -- an out-of-image unit reads
   // a clamped in-image address and is zeroed by a select (BORDER_CONSTANT 0) -- so the compiler can count vmcnt
   // instead of draining it.  Buffer addressing: a per-frame descriptor (scalar arithmetic) + the thread's constant
   // 32-bit offsets.
   typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
-  struct Regs { u32x3_t q[ST_SLOTS]; };
-  bool slot_any[ST_SLOTS];
+  struct Regs { u32x3_t q[SLOTS]; };
+  bool slot_any[SLOTS];
 #pragma unroll
-  for (int sl = 0; sl < ST_SLOTS; ++sl) slot_any[sl] = __any(uact[sl]);     // wave-uniform
+  for (int sl = 0; sl < SLOTS; ++sl) slot_any[sl] = __any(uact[sl]);     // wave-uniform
   auto issue = [&](int f, Regs& r) {
     const int fc = min(f, f1 - 1);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(frames + (size_t)fc * frame_bytes), 0, (int)frame_bytes, 0x00020000);
 #pragma unroll
-    for (int sl = 0; sl < ST_SLOTS; ++sl) {
+    for (int sl = 0; sl < SLOTS; ++sl) {
       if (!slot_any[sl]) continue;
       if (NCH == 3) r.q[sl] = __builtin_amdgcn_raw_buffer_load_b96(rs, uoff[sl], 0, 0);
       else r.q[sl].x = __builtin_amdgcn_raw_buffer_load_b32(rs, uoff[sl], 0, 0);
@@ -306,14 +316,14 @@ __device__ __forceinline__ void ingest_staged_body(const uint8_t* __restrict__ f
   };
   auto commit = [&](uint8_t* buf, const Regs& r) {
 #pragma unroll
-    for (int sl = 0; sl < ST_SLOTS; ++sl) {
+    for (int sl = 0; sl < SLOTS; ++sl) {
       if (!slot_any[sl]) continue;
       uint32_t g4 = (NCH == 3) ? rcc_grey4<RGB>(r.q[sl].x, r.q[sl].y, r.q[sl].z) : r.q[sl].x;
       if (!uin[sl]) g4 = 0;
       *reinterpret_cast<uint32_t*>(buf + ulds[sl]) = g4;
     }
   };
-  const int out_off = y * w + x0;
+  const int out_off = inside ? y * w + x0 : 0x7FFFFFF0;          // beyond the descriptor's range: the hardware drops the store
   auto taps = [&](int f, const uint8_t* L) {
     uint32_t sv[4];
 #pragma unroll

@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void k_ingest_gather(const uint8_t* __restrict
   }
 }
 
-template <int NCH, bool RGB = false>
-__global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict__ frames,
+template <int NCH, bool RGB = false, int TH = ST_TH>
+__global__ __launch_bounds__(32 * TH) void k_ingest_staged(const uint8_t* __restrict__ frames,
                                                        int64_t frame_bytes, int stride, int w, int h,
                                                        rcc_cam cam, uint8_t* __restrict__ grey,
                                                        int nframes, int fpb, int ntx, int ntiles, int per_xcd,
@@ -76,21 +76,22 @@ __global__ __launch_bounds__(256) void k_ingest_staged(const uint8_t* __restrict
   const int bz = kk / per_xcd;
   const int tile = xcd * per_xcd + (kk - bz * per_xcd);
   if (tile >= ntiles) return;                       // block-uniform
-  __shared__ __attribute__((aligned(16))) uint8_t lds[ST_TILE_LDS];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[ST_TILE_LDS_T(TH)];
   __shared__ int s_flag[2];
-  ingest_staged_body<NCH, RGB>(frames, frame_bytes, stride, w, h, cam, grey, nframes, fpb, ntx, tile, bz, threadIdx.x, lds, s_flag, 0, 1, map, tilebox);
+  ingest_staged_body<NCH, RGB, TH>(frames, frame_bytes, stride, w, h, cam, grey, nframes, fpb, ntx, tile, bz, threadIdx.x, lds, s_flag, 0, 1, map, tilebox);
 }
 
 // The frame-invariant part of the staged pass, once per handle: map[v * w + u] = Q5 source coordinates of destination
 // pixel (u, v) (rcc_map_q5, the arithmetic of the specification), and per 128 x 8 destination tile the bounding box of
 // the integer source coordinates (min x, max x, min y, max y) -- what ingest_staged_body otherwise recomputes per block.
-__global__ __launch_bounds__(256) void k_ingest_map(int w, int h, rcc_cam cam, int ntx, int2* __restrict__ map, int4* __restrict__ tilebox)
+template <int TH>
+__global__ __launch_bounds__(32 * TH) void k_ingest_map(int w, int h, rcc_cam cam, int ntx, int2* __restrict__ map, int4* __restrict__ tilebox)
 {
-  __shared__ int s_red[4][4];
+  __shared__ int s_red[TH / 2][4];
   const int tile = blockIdx.x, tid = threadIdx.x;
   const int by = tile / ntx, bx = tile - by * ntx;
   const int tx = tid & 31, ty = tid >> 5;
-  const int x0 = bx * ST_TW + tx * 4, y = by * ST_TH + ty;
+  const int x0 = bx * ST_TW + tx * 4, y = by * TH + ty;
   const bool inside = (y < h) && (x0 < w);
   int mnx = INT32_MAX, mxx = INT32_MIN, mny = INT32_MAX, mxy = INT32_MIN;
 #pragma unroll
@@ -110,9 +111,11 @@ __global__ __launch_bounds__(256) void k_ingest_map(int w, int h, rcc_cam cam, i
   }
   if ((tid & 63) == 0) { s_red[tid >> 6][0] = mnx; s_red[tid >> 6][1] = mxx; s_red[tid >> 6][2] = mny; s_red[tid >> 6][3] = mxy; }
   __syncthreads();
-  if (tid == 0)
-    tilebox[tile] = make_int4(min(min(s_red[0][0], s_red[1][0]), min(s_red[2][0], s_red[3][0])), max(max(s_red[0][1], s_red[1][1]), max(s_red[2][1], s_red[3][1])),
-                              min(min(s_red[0][2], s_red[1][2]), min(s_red[2][2], s_red[3][2])), max(max(s_red[0][3], s_red[1][3]), max(s_red[2][3], s_red[3][3])));
+  if (tid == 0) {
+    int4 b = make_int4(s_red[0][0], s_red[0][1], s_red[0][2], s_red[0][3]);
+    for (int q = 1; q < TH / 2; ++q) { b.x = min(b.x, s_red[q][0]); b.y = max(b.y, s_red[q][1]); b.z = min(b.z, s_red[q][2]); b.w = max(b.w, s_red[q][3]); }
+    tilebox[tile] = b;
+  }
 }
 
 // ---- no undistortion: pure streaming conversion -----------------------------------------------
@@ -187,24 +190,37 @@ hipError_t rcc_ingest_staged_plan(rcc_handle* h, const uint8_t* d_frames, int nf
   if (variant < 0) variant = staged_ok ? 1 : 0;
   if (variant != 1 || !staged_ok) return hipSuccess;
   p->cam = make_cam(c);
+  // tile height: 16 rows (1.16 instead of 1.25 source rows per destination row; measured on 256 x 4K fisheye: 1.735 -> 1.589 ms),
+  // unless the 8-row form is asked for (rcc_set_ingest_variant(3): A/B, tests)
+#ifdef RCC_EXPERIMENTS
+  static const int th_env = getenv("RCC_INGEST_TH") ? atoi(getenv("RCC_INGEST_TH")) : 0;
+#else
+  const int th_env = 0;
+#endif
+  const int TH = h->ingest_tile8 ? ST_TH : (th_env == 32 && ht >= 32) ? 32 : (ht >= 16 && th_env != 8) ? 16 : ST_TH;       // (a height of 8 mod 16: the last tile row's lower half is idle)
+  p->th = TH;
 #ifdef RCC_EXPERIMENTS
   static const int fpb_max = getenv("RCC_INGEST_FPB") ? atoi(getenv("RCC_INGEST_FPB")) : 32;
 #else
   const int fpb_max = 32;
 #endif
   int fpb = fpb_max;
-  const int tiles = ((w + ST_TW - 1) / ST_TW) * ((ht + ST_TH - 1) / ST_TH);
-  while (fpb > 2 && (int64_t)tiles * ((nframes + fpb - 1) / fpb) < 4096) fpb >>= 1;
+  const int tiles = ((w + ST_TW - 1) / ST_TW) * ((ht + TH - 1) / TH);
+  while (fpb > 2 && (int64_t)tiles * ((nframes + fpb - 1) / fpb) < 4096 * ST_TH / TH) fpb >>= 1;
   p->fpb = fpb; p->tiles = tiles;
   p->ntx = (w + ST_TW - 1) / ST_TW; p->per_xcd = (tiles + 7) / 8; p->ngroups = (nframes + fpb - 1) / fpb;
-  if (!h->d_map && !h->map_failed) {
-    // first staged launch of this handle: tabulate the map (w * h * 8 B) and the tiles' source boxes
-    if (hipMalloc((void**)&h->d_map, (size_t)w * ht * sizeof(int2)) != hipSuccess || hipMalloc((void**)&h->d_tilebox, (size_t)tiles * sizeof(int4)) != hipSuccess) {
+  if ((!h->d_map || h->map_th != TH) && !h->map_failed) {
+    // first staged launch of this handle (or the first with this tile height): tabulate the map (w * h * 8 B) and the tiles'
+    // source boxes
+    if (h->d_tilebox) { (void)hipStreamSynchronize(s); (void)hipFree(h->d_tilebox); h->d_tilebox = nullptr; }
+    if ((!h->d_map && hipMalloc((void**)&h->d_map, (size_t)w * ht * sizeof(int2)) != hipSuccess) || hipMalloc((void**)&h->d_tilebox, (size_t)tiles * sizeof(int4)) != hipSuccess) {
       if (h->d_map) (void)hipFree(h->d_map);
       h->d_map = nullptr; h->d_tilebox = nullptr; h->map_failed = 1;      // no room: the kernel recomputes the map itself
       (void)hipGetLastError();
     } else {
-      hipLaunchKernelGGL(k_ingest_map, dim3(tiles), dim3(256), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
+      if (TH == 32) hipLaunchKernelGGL(k_ingest_map<32>, dim3(tiles), dim3(1024), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
+      else if (TH == 16) hipLaunchKernelGGL(k_ingest_map<16>, dim3(tiles), dim3(512), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
+      else hipLaunchKernelGGL(k_ingest_map<ST_TH>, dim3(tiles), dim3(256), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
       hipError_t em = hipGetLastError();
       if (em == hipSuccess) em = hipStreamSynchronize(s);      // once per handle: later launches may come on other streams
       if (em != hipSuccess) {
@@ -213,6 +229,7 @@ hipError_t rcc_ingest_staged_plan(rcc_handle* h, const uint8_t* d_frames, int nf
         h->d_map = nullptr; h->d_tilebox = nullptr; h->map_failed = 1;
         return em;
       }
+      h->map_th = TH;
     }
   }
   p->map = h->ingest_table ? h->d_map : nullptr;
@@ -256,15 +273,25 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
     if (e != hipSuccess) return e;
     if (staged) {
       dim3 grid(8 * p.per_xcd * p.ngroups);
-      if (c.pixfmt == RCC_PIX_RGB8)
-        hipLaunchKernelGGL((k_ingest_staged<3, true>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, p.cam, d_grey, nframes, p.fpb, p.ntx, p.tiles, p.per_xcd,
-                           (const int2*)p.map, (const int4*)p.tilebox);
-      else if (c.pixfmt == RCC_PIX_BGR8)
-        hipLaunchKernelGGL((k_ingest_staged<3>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, p.cam, d_grey, nframes, p.fpb, p.ntx, p.tiles, p.per_xcd,
-                           (const int2*)p.map, (const int4*)p.tilebox);
-      else
-        hipLaunchKernelGGL((k_ingest_staged<1>), grid, dim3(256), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, p.cam, d_grey, nframes, p.fpb, p.ntx, p.tiles, p.per_xcd,
-                           (const int2*)p.map, (const int4*)p.tilebox);
+#define LAUNCH_STAGED(NCH_, RGB_, TH_) hipLaunchKernelGGL((k_ingest_staged<NCH_, RGB_, TH_>), grid, dim3(32 * TH_), 0, s, d_frames, c.frame_bytes, c.stride_bytes, w, ht, \
+                                                          p.cam, d_grey, nframes, p.fpb, p.ntx, p.tiles, p.per_xcd, (const int2*)p.map, (const int4*)p.tilebox)
+#ifdef RCC_EXPERIMENTS
+      if (p.th == 32) {
+        if (c.pixfmt == RCC_PIX_RGB8) LAUNCH_STAGED(3, true, 32);
+        else if (c.pixfmt == RCC_PIX_BGR8) LAUNCH_STAGED(3, false, 32);
+        else LAUNCH_STAGED(1, false, 32);
+      } else
+#endif
+      if (p.th == 16) {
+        if (c.pixfmt == RCC_PIX_RGB8) LAUNCH_STAGED(3, true, 16);
+        else if (c.pixfmt == RCC_PIX_BGR8) LAUNCH_STAGED(3, false, 16);
+        else LAUNCH_STAGED(1, false, 16);
+      } else {
+        if (c.pixfmt == RCC_PIX_RGB8) LAUNCH_STAGED(3, true, ST_TH);
+        else if (c.pixfmt == RCC_PIX_BGR8) LAUNCH_STAGED(3, false, ST_TH);
+        else LAUNCH_STAGED(1, false, ST_TH);
+      }
+#undef LAUNCH_STAGED
       return hipGetLastError();
     }
   }

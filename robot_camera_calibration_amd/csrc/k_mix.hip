@@ -71,7 +71,10 @@ hipError_t rcc_launch_mix(rcc_handle* h, const uint8_t* d_frames, int n_in, uint
   int ki = 0;
   if (n_in > 0) {
     bool staged = false;
+    const int tile8 = h->ingest_tile8;
+    h->ingest_tile8 = 1;                 // this launch's ingest role runs 128 x 8 tiles in 256-thread workgroups
     hipError_t e = rcc_ingest_staged_plan(h, d_frames, n_in, s, &ip, &staged);
+    h->ingest_tile8 = tile8;
     if (e != hipSuccess) return e;
     if (!staged) return hipSuccess;
     ki = ip.per_xcd * ip.ngroups;

@@ -321,15 +321,17 @@ int rcc_set_pnp_mfma(rcc_handle* h, int on)
   h->pnp_use_mfma = on ? 1 : 0;
   return p;
 }
-// variant: 0 gather, 1 staged with the tabulated map (default where the geometry allows), 2 staged recomputing the map
-// per block; -1 automatic
+// variant: 0 gather, 1 staged with the tabulated map (default where the geometry allows: 128 x 16 tiles), 2 staged recomputing the map per block (128 x 8 tiles), 3 staged with the tabulated map and
+// 128 x 8 tiles; -1 automatic
 int rcc_set_ingest_variant(rcc_handle* h, int variant)
 {
   if (!h) return RCC_ERR_ARG;
   int p = h->ingest_variant;
   if (p == 1 && !h->ingest_table) p = 2;
+  else if (p == 1 && h->ingest_tile8) p = 3;
   h->ingest_table = (variant == 2) ? 0 : 1;
-  h->ingest_variant = (variant == 2) ? 1 : variant;
+  h->ingest_tile8 = (variant == 2 || variant == 3) ? 1 : 0;
+  h->ingest_variant = (variant == 2 || variant == 3) ? 1 : variant;
   return p;
 }
 
@@ -565,7 +567,7 @@ static int launch_host_pipeline(rcc_handle* h, const uint8_t* host_frames, int n
     v.want_thr = h->keep_bin ? 0 : 1;
     if (v.dense_variant == 3) v.dense_variant = 1;      // (one flat-mask buffer per handle: see the chunked device path)
     hipError_t e = rcc_launch_ingest(&v, h->d_stage + (size_t)f0 * fb, f1 - f0, v.d_grey, s);
-    h->d_map = v.d_map; h->d_tilebox = v.d_tilebox; h->map_failed = v.map_failed;     // tables built by the first launch belong to the handle
+    h->d_map = v.d_map; h->d_tilebox = v.d_tilebox; h->map_failed = v.map_failed; h->map_th = v.map_th;     // tables built by the first launch belong to the handle
     if (e == hipSuccess) e = rcc_launch_dense(&v, v.d_grey, f1 - f0, v.d_bin, v.d_cand, v.d_cand_count, s);
     if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s", hipGetErrorString(e)); return RCC_ERR_DEVICE; }
     h->dense_kernel = v.dense_kernel;
@@ -624,7 +626,7 @@ int rcc_detect_batch(rcc_handle* h, const void* frames, int32_t nframes, int32_t
       if (v.dense_variant == 3) v.dense_variant = 1;
       hipStream_t cs = h->pstream[c & 1];
       hipError_t e = rcc_launch_ingest(&v, d_frames + (size_t)f0 * h->cfg.frame_bytes, f1 - f0, v.d_grey, cs);
-      h->d_map = v.d_map; h->d_tilebox = v.d_tilebox; h->map_failed = v.map_failed;     // tables built by the first launch belong to the handle
+      h->d_map = v.d_map; h->d_tilebox = v.d_tilebox; h->map_failed = v.map_failed; h->map_th = v.map_th;     // tables built by the first launch belong to the handle
       if (e == hipSuccess) e = rcc_launch_dense(&v, v.d_grey, f1 - f0, v.d_bin, v.d_cand, v.d_cand_count, cs);
       if (e != hipSuccess) { snprintf(h->err, sizeof(h->err), "%s", hipGetErrorString(e)); return RCC_ERR_DEVICE; }
       int r = launch_targets(&v, v.d_grey, v.d_bin, v.d_cand, v.d_cand_count, f1 - f0, cs, nullptr);

@@ -72,6 +72,8 @@ struct rcc_handle {
   void* d_map;              // staged ingest: Q5 map of the handle's camera (w * h int2) and the tiles' source boxes (int4 each),
   void* d_tilebox;          //   tabulated at the first staged launch (k_ingest_map)
   int map_failed;           // the tables could not be allocated: the kernel recomputes the map per block
+  int map_th;               // tile height the source boxes in d_tilebox were tabulated for (8 or 16)
+  int ingest_tile8;         // rcc_set_ingest_variant(3): staged with 128 x 8 tiles even where 128 x 16 fit (A/B, tests)
   int ingest_table;         // 1 (default): use the tables; 0: recompute (A/B, tests)
   int fuse_grid_pnp;        // 1 (default): board validation / indexing and pose in one kernel (checkerboard, wave-per-board solver)
   int keep_bin;             // rcc_set_keep_binary: rcc_detect_batch writes the full binary image (default 0: the compact map)
@@ -147,6 +149,7 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
 struct rcc_ingest_plan {
   rcc_cam cam;
   int fpb, ntx, tiles, per_xcd, ngroups;     // frames per workgroup, tiles per row, tiles, tiles per XCD, frame groups
+  int th;                                    // tile height: 8 or 16 destination rows (128 columns)
   const void* map; const void* tilebox;      // the tabulated Q5 map and the tiles' source boxes (null: recomputed per workgroup)
 };
 struct rcc_wave_plan {

@@ -8,6 +8,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
+EXP = os.path.basename(os.environ.get('RCC_LIBRARY', '')) == 'librcc_hip_exp.so'     # the gang form (and a real variant 3) exist only there
 from robot_camera_calibration_amd import abi, api, synth
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -58,9 +59,10 @@ while time.time() - t0 < budget:
         f1 = torch.randint(0, 256, (n, padded.frame_bytes), dtype=torch.uint8, device="cuda:0")
         f1[:, :stride * h].view(n, h, stride)[:, :, :w * ch] = f0.view(n, h, w * ch)
         d1 = api.Detector(padded)
-        sw = dict(dense=int(rng.choice([-1, 0, 1, 2, 3, 4])), skip=int(rng.integers(2)), gang=int(rng.choice([0, 0, 1, 4, 16])), ingest=int(rng.choice([-1, 0, 1, 2])),
+        sw = dict(dense=int(rng.choice([-1, 0, 1, 2, 3, 4])), skip=int(rng.integers(2)), gang=int(rng.choice([0, 0, 1, 4, 16])) if EXP else 0, ingest=int(rng.choice([-1, 0, 1, 2, 3])),
                   fuse=int(rng.integers(2)), pipe=int(rng.choice([0, 0, 2, 3])), pnp=int(rng.choice([-1, 1])), keep=int(rng.integers(2)), grid=int(rng.choice([0, 1, 5, 64])))
-        d1.set_dense_variant(sw["dense"]); d1.set_dense_skip(sw["skip"]); d1.set_dense_gang(sw["gang"]); d1.set_ingest_variant(sw["ingest"])
+        d1.set_dense_variant(sw["dense"]); d1.set_dense_skip(sw["skip"]); d1.set_ingest_variant(sw["ingest"])
+        if EXP: d1.set_dense_gang(sw["gang"])
         d1.set_fuse_grid_pnp(sw["fuse"]); d1.set_pipeline(sw["pipe"]); d1.set_pnp_variant(sw["pnp"]); d1.set_keep_binary(sw["keep"]); d1.set_subpix_grid(sw["grid"])
         desc.update(sw)
         for rep in range(2):
