@@ -53,6 +53,7 @@ int orc_filter_candidates(const orc_cand* in, int n, const uint8_t* bin, int w, 
                           int nms_radius, int xj_check, orc_cand* out, int cap);
 int orc_xjunction_ring(const uint8_t* bin, int w, int h, int x, int y);
 int orc_xjunction_ring_grey(const uint8_t* grey, int w, int h, int x, int y, int min_contrast);
+int orc_junction_pretest(const uint8_t* grey, int w, int h, int x, int y, int min_contrast);
 
 /* ---- a5 sub-pixel ---- */
 void orc_corner_subpix(const uint8_t* grey, int w, int h, const orc_cand* pts, int n,

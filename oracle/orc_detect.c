@@ -117,6 +117,13 @@ int orc_ctx_detect(orc_ctx* c, const uint8_t* frame, int frame_index, rcc_detect
         orc_corner_subpix(c->grey, w, h, c->pre + i, 1, cfg->subpix_win, it, eps, pxy + 2 * i);
       else { pxy[2 * i] = (double)c->pre[i].x; pxy[2 * i + 1] = (double)c->pre[i].y; }
     }
+  } else if (cfg->xj_check && cfg->target_kind == RCC_TARGET_CHECKERBOARD) {
+    /* board scenes: only what can be a junction is refined (orc_junction_pretest); the others reach a4.3 as (-1, -1) */
+    for (int i = 0; i < npre; ++i) {
+      if (orc_junction_pretest(c->grey, w, h, c->pre[i].x, c->pre[i].y, cfg->thr_min_contrast))
+        orc_corner_subpix(c->grey, w, h, c->pre + i, 1, cfg->subpix_win, cfg->subpix_max_iter, cfg->subpix_eps, pxy + 2 * i);
+      else { pxy[2 * i] = -1.0; pxy[2 * i + 1] = -1.0; }
+    }
   } else {
     orc_corner_subpix(c->grey, w, h, c->pre, npre, cfg->subpix_win, cfg->subpix_max_iter, cfg->subpix_eps, pxy);
   }

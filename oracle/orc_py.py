@@ -45,6 +45,7 @@ def _bind(so):
     L.orc_find_homography.restype = C.c_int
     L.orc_xjunction_ring.restype = C.c_int
     L.orc_xjunction_ring_grey.restype = C.c_int
+    L.orc_junction_pretest.restype = C.c_int
     return L
 
 

@@ -20,6 +20,13 @@
 // per wave costs more in the launch's tail than the ~15 saved loads.)  Tag scenes (FID = true): grid (qstep, nframes) with
 // qstep well below the list's length; a wave walks its frame's list four candidates at a time -- see below and
 // rcc_launch_subpix.
+// a5's gate for board scenes: 16 samples on a radius-8 ring
+// around the candidate's own pixel against the ring's mid level
+__constant__ int8_t c_ring8[16][2] = {
+  { 8, 0}, { 7, 3}, { 6, 6}, { 3, 7}, { 0, 8}, {-3, 7}, {-6, 6}, {-7, 3},
+  {-8, 0}, {-7,-3}, {-6,-6}, {-3,-7}, { 0,-8}, { 3,-7}, { 6,-6}, { 7,-3}
+};
+
 template <bool FID>       // FID: tag scenes (the convex-black-corner test in front of the refinement, waves walk the candidate list)
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
@@ -32,6 +39,32 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   if ((int)blockIdx.x >= np) return;
   const int lane = threadIdx.x;
   const uint8_t* g = grey + (size_t)f * w * h;
+  if (!FID && fid_min_contrast >= 0) {
+    // Board scenes: is the candidate worth refining?  The 36 L-shaped corners on the outline of a 9 x 7-square board took 42 % of
+    // this stage's iterations only to be rejected by a4.3.  Lanes 0..15 read the radius-8 ring around the candidate's pixel (a
+    // Harris maximum sits up to ~3 px off its junction: the ring still encloses it); fewer than four transitions against the
+    // ring's own mid level, or a ring that does not span min_contrast: not a junction -- the wave writes (-1, -1), which a4.3
+    // rejects, and retires before it has loaded its tables.  A ring that leaves the image passes.
+    const rcc_cand c0 = pre[(size_t)f * kstride + blockIdx.x];
+    const int xi = c0.x, yi = c0.y;
+    if (xi >= 8 && yi >= 8 && xi < w - 8 && yi < h - 8) {                         // wave-uniform
+      const int k = lane & 15;
+      const int v = (int)g[(size_t)(yi + c_ring8[k][1]) * w + (xi + c_ring8[k][0])];
+      int lo = v, hi = v;
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+      const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(v > ((lo + hi) >> 1)) & 0xFFFFu;
+      const unsigned rotl = ((bits << 1) | (bits >> 15)) & 0xFFFFu;
+      const int lo0 = __builtin_amdgcn_readfirstlane(lo), hi0 = __builtin_amdgcn_readfirstlane(hi);
+      if (hi0 - lo0 < fid_min_contrast || __popc(bits ^ rotl) < 4) {
+        if (lane == 0) {
+          pre_xy[((size_t)f * kstride + blockIdx.x) * 2] = -1.0;
+          pre_xy[((size_t)f * kstride + blockIdx.x) * 2 + 1] = -1.0;
+        }
+        return;
+      }
+    }
+  }
   const int win = sp.win;
   const int ww = 2 * win + 1, pw = 2 * win + 3;
   // per-lane sample tables (the window geometry does not change between corners or iterations): patch samples
@@ -213,6 +246,7 @@ hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, 
                        h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy, c.thr_min_contrast > 0 ? c.thr_min_contrast : 0, qstep);
   else
     hipLaunchKernelGGL(k_subpix<false>, dim3(qstep, nframes), dim3(64), 0, s, d_grey, c.width, c.height,
-                       h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy, -1, qstep);
+                       h->d_pre, h->d_npre, h->sp, h->d_sp_tab, h->kept_cap, h->d_pre_xy,
+                       (c.xj_check && c.target_kind == RCC_TARGET_CHECKERBOARD) ? (c.thr_min_contrast > 0 ? c.thr_min_contrast : 0) : -1, qstep);
   return hipGetLastError();
 }

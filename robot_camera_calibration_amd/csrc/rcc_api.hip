@@ -127,7 +127,10 @@ void rcc_destroy(rcc_handle* h)
   if (h->h_ndet) (void)hipHostFree(h->h_ndet);
   if (h->h_det2) (void)hipHostFree(h->h_det2);
   if (h->h_ndet2) (void)hipHostFree(h->h_ndet2);
+  for (auto& ps : h->pstream) if (ps) (void)hipStreamSynchronize(ps);
   for (auto& e : h->sub_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->fc_ready) if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->fc_done) if (e) (void)hipEventDestroy(e);
   for (auto& p : h->sub_t_ev) for (auto& e : p) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -209,6 +212,8 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
       hipHostMalloc((void**)&h->h_det2, B * (size_t)cfg->max_targets * sizeof(rcc_detection)) != hipSuccess ||
       hipHostMalloc((void**)&h->h_ndet2, B * sizeof(int32_t)) != hipSuccess) { rcc_destroy(h); return RCC_ERR_NOMEM; }
   for (auto& e : h->sub_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
+  for (auto& e : h->fc_ready) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
+  for (auto& e : h->fc_done) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   for (auto& p : h->sub_t_ev) for (auto& e : p) if (hipEventCreate(&e) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   for (float& m : h->last_step_ms) m = -1.0f;
   {
@@ -439,6 +444,17 @@ static int launch_targets(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d
   return RCC_OK;
 }
 
+// The previous submission's corner tables may still be on their way to the host (copy stream): the list stage is the first kernel
+// that writes d_fc again, so the stream that is about to launch it waits for that copy (a device-side wait, long satisfied by then).
+static int wait_corner_copy(rcc_handle* h, hipStream_t s)
+{
+  if (h->fc_pending) {
+    HIPCHK(h, hipStreamWaitEvent(s, h->fc_done[h->fc_pending - 1], 0));
+    h->fc_pending = 0;
+  }
+  return RCC_OK;
+}
+
 // device -> host copy of the records, synchronise, compact into the caller's array
 static int collect_targets(rcc_handle* h, int nframes, rcc_detection* det, int32_t* ndet, rcc_frame_corners* corners,
                            hipStream_t s, bool timed)
@@ -543,6 +559,7 @@ static int launch_host_pipeline(rcc_handle* h, const uint8_t* host_frames, int n
 {
   const size_t fb = (size_t)h->cfg.frame_bytes;
   const int nchunks = (nframes + per - 1) / per;
+  { int rw = wait_corner_copy(h, s); if (rw != RCC_OK) return rw; }
   // the staging buffer and the per-frame buffers are this handle's only set: the copies wait for everything queued on s
   HIPCHK(h, hipEventRecord(h->pev[0], s));
   for (int k = 0; k < 2; ++k) HIPCHK(h, hipStreamWaitEvent(h->pstream[k], h->pev[0], 0));
@@ -701,6 +718,7 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
     h->want_thr = h->keep_bin ? 0 : 1;
     HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
     h->want_thr = 0;
+    { int rw = wait_corner_copy(h, s); if (rw != RCC_OK) return rw; }
     int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, &tev[2]);
     if (r != RCC_OK) return r;
   }
@@ -709,7 +727,14 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   int32_t* hn = slot ? h->h_ndet2 : h->h_ndet;
   HIPCHK(h, hipMemcpyAsync(hd, h->d_det, sizeof(rcc_detection) * (size_t)nframes * (fid ? slots : 1), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemcpyAsync(hn, h->d_ndet, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost, s));
-  if (corners) HIPCHK(h, hipMemcpyAsync(corners, h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, s));
+  h->sub_has_fc[slot] = corners ? 1 : 0;
+  if (corners) {
+    HIPCHK(h, hipEventRecord(h->fc_ready[slot], s));
+    HIPCHK(h, hipStreamWaitEvent(h->pstream[0], h->fc_ready[slot], 0));
+    HIPCHK(h, hipMemcpyAsync(corners, h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, h->pstream[0]));
+    HIPCHK(h, hipEventRecord(h->fc_done[slot], h->pstream[0]));
+    h->fc_pending = slot + 1;
+  }
   HIPCHK(h, hipEventRecord(tev[5], s));
   HIPCHK(h, hipEventRecord(h->sub_ev[slot], s));
   h->sub_t_seq[ring] = h->sub_head + 1u;
@@ -730,6 +755,10 @@ int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet)
   HIPCHK(h, hipSetDevice(h->device));
   const int slot = (int)(h->sub_tail & 1u);
   HIPCHK(h, hipEventSynchronize(h->sub_ev[slot]));
+  if (h->sub_has_fc[slot]) {          // the corner tables came over on the copy stream
+    HIPCHK(h, hipEventSynchronize(h->fc_done[slot]));
+    if (h->fc_pending == slot + 1) h->fc_pending = 0;
+  }
   const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
   const int slots = h->cfg.max_targets, nframes = h->sub_nframes[slot];
   const rcc_detection* hd = slot ? h->h_det2 : h->h_det;

@@ -102,6 +102,13 @@ struct rcc_handle {
   rcc_detection* h_det2;
   int32_t* h_ndet2;
   hipEvent_t sub_ev[2];     // results of the submission in slot i are in pinned memory
+  // the per-frame corner tables of a submission (rcc_frame_corners, 6 KB per frame) go to the host on a copy stream, under the
+  // next batch's ingest and threshold + corner passes: fc_ready[i] = the tables of slot i are complete (on the batch's stream),
+  // fc_done[i] = they are in the caller's memory (on the copy stream); the next batch's list stage, the first kernel that writes
+  // d_fc again, waits for fc_done
+  hipEvent_t fc_ready[2], fc_done[2];
+  int fc_pending;           // slot + 1 of a corner-table copy the next launch_targets must wait for; 0 none
+  unsigned char sub_has_fc[2];
   // timing events of the streaming form, a ring over the last RCC_SUBT_RING submissions (submission n uses entry n mod ring, so the
   // previous submission's end is still readable when this one is collected): [0] the stream reaches the batch, [1] ingest done,
   // [2] threshold + corner pass done, [3] list + sub-pixel (+ quads) done, [4] pose done, [5] records in pinned host memory

@@ -241,6 +241,60 @@ def test_xjunction_ring_grey(oracle):
             assert ringg(img, x, y) == exp
 
 
+def test_junction_pretest_gate(oracle):
+    """a5's gate for board scenes (round 4): a radius-8 grey ring around the UNREFINED pixel against its own mid level -- four or
+    more transitions pass (a junction, also seen from up to 3 px off), fewer do not (an L-corner, a straight edge, a plain area);
+    a ring that leaves the image passes; and an independent whole-array derivation on random patches"""
+    L = oracle.lib()
+    P = lambda a: a.ctypes.data_as(oracle.C.c_void_p)
+    gate = lambda gg, x, y, mc=16: L.orc_junction_pretest(P(gg), gg.shape[1], gg.shape[0], x, y, mc)
+    g = _saddle(x0=32, y0=32, ang=0.2)
+    for dx, dy in ((0, 0), (3, 0), (-2, 2), (0, -3), (2, 2)):
+        assert gate(g, 32 + dx, 32 + dy) == 1
+    lc = np.full((64, 64), 233, np.uint8); lc[32:, :32] = 22                    # L-shaped corner of one black square
+    for dx, dy in ((0, 0), (2, -1), (-3, 2)):
+        assert gate(lc, 32 + dx, 32 + dy) == 0
+    e = np.full((64, 64), 20, np.uint8); e[:, 32:] = 235
+    assert gate(e, 32, 32) == 0 and gate(np.full((64, 64), 128, np.uint8), 32, 32) == 0
+    assert gate(lc, 5, 30) == 1 and gate(lc, 32, 60) == 1                       # the ring leaves the image: a5 and a4.3 decide
+    ang = 2 * np.pi * np.arange(16) / 16
+    ring = np.stack([np.rint(8.0 * np.cos(ang)), np.rint(8.0 * np.sin(ang))], 1).astype(int)
+    for seed in range(80):
+        r2 = np.random.default_rng(300 + seed)
+        img = _saddle(x0=20 + r2.uniform(-3, 3), y0=20 + r2.uniform(-3, 3), ang=r2.uniform(0, 3), w=40, h=40) if seed % 2 else r2.integers(0, 256, (40, 40)).astype(np.uint8)
+        img = np.clip(img.astype(int) + r2.integers(-12, 13, img.shape), 0, 255).astype(np.uint8)
+        for (x, y) in ((20, 20), (17, 23), (12, 28)):
+            v = img[y + ring[:, 1], x + ring[:, 0]].astype(int)
+            bits = v > ((v.min() + v.max()) // 2)
+            assert gate(img, x, y) == int(v.max() - v.min() >= 16 and (bits != np.roll(bits, -1)).sum() >= 4)
+
+
+def test_junction_gate_holds_back_the_outline_not_the_corners(oracle):
+    """on rendered boards (ideal, and sigma 1.5 + shading) the gate holds back every candidate on the board's outline and none that
+    a4.3 would validate: same 48 corners, same pose as with the gate off (xj_check = 0 switches gate and junction tests off, so the
+    comparison refines the same candidates by hand)"""
+    cfg = oracle.default_config()
+    abi.set_geometry(cfg, 640, 480, abi.RCC_PIX_BGR8)
+    for optics in (None, (1.5, 300, -200, 400)):
+        sp = abi.default_synth_params(seed=21)
+        if optics:
+            abi.set_optics(sp, *optics)
+        poses = synth.sample_poses(3, cfg, seed=21)
+        ctx = oracle.Context(cfg)
+        for f in range(3):
+            img = oracle.synth_render(cfg, sp, poses[f], f)
+            n, det, fc, st = ctx.detect(img, f, stages=True)
+            assert n == 1 and fc.ncorners == 48
+            pre, xy = st["pre"][:st["npre"]], st["pre_xy"]
+            held = (xy == -1.0).all(1)
+            full = oracle.corner_subpix(st["grey"], pre, cfg.subpix_win, cfg.subpix_max_iter, cfg.subpix_eps)
+            assert (xy[~held] == full[~held]).all()                            # what is refined is refined as before
+            kept_all, kxy_all, m = oracle.validate_refined(pre, full, st["bin"], st["grey"], 1, cfg.thr_min_contrast)
+            assert m == st["nkept"] and (kept_all["x"] == st["kept"]["x"][:m]).all() and (kept_all["y"] == st["kept"]["y"][:m]).all()
+            assert held.sum() >= 30                                            # the outline: 36 candidates on an ideal render
+        ctx.close()
+
+
 # ---------------------------------------------------------------- a5
 @pytest.mark.parametrize("x0,y0,ang", [(31.3, 30.6, 0.3), (32.0, 32.0, 0.0), (30.75, 33.4, 0.9), (33.49, 29.51, -0.5)])
 def test_subpix_converges_to_saddle(oracle, x0, y0, ang):
