@@ -113,7 +113,7 @@ typedef struct rcc_config {
   int32_t cand_margin;      /* candidates keep this many pixels from the image border (>= 8) */
   int32_t max_candidates;   /* per-frame capacity of the dense pass's output list */
   int32_t nms_radius;       /* list-level suppression radius (Chebyshev), pixels */
-  int32_t xj_check;         /* 1: board scenes keep only X-junctions: a5 refines only candidates whose radius-8 grey ring shows >= 4
+  int32_t xj_check;         /* 1: board scenes keep only X-junctions: a5 refines only candidates whose radius-11 grey ring shows >= 4
                                transitions, a4.3 validates on two radius-5 rings at the refined pixel; 0: every
                                suppressed candidate is refined and kept */
   int32_t max_kept;         /* per-frame capacity after suppression + validation (<= 256) */

@@ -372,22 +372,23 @@ int orc_xjunction_ring_grey(const uint8_t* grey, int w, int h, int x, int y, int
 
 /* a5's gate for board scenes [B] (round 4): is the candidate worth refining?  Besides its 48 inner corners a 9 x 7-square board
  * raises 36 Harris candidates on its outline -- L-shaped corners of single squares against the white margin -- which a5 refined at
- * the cost of the true ones (4-5 iterations each: 42 % of the stage's work) only for a4.3 to reject them.  A radius-8 ring around the
- * UNREFINED pixel (a Harris maximum sits up to ~3 px off its junction: the ring still encloses it) read against its own mid level
- * shows four or more transitions at a junction and two at an L-corner or an edge.  Candidates that show fewer than four are not
- * refined and reach a4.3 as (-1, -1), which it rejects.  A ring that leaves the image passes (a5 and a4.3 decide).  Measured on 60
- * oracle frames (640x480 and 1280x720; ideal, sigma 1.5 + shading, sigma 2): no inner corner held back, every outline candidate held
- * back; with radius 5-7 blurred junctions were lost (scratch note in DESIGN.md section 3). */
-static const int8_t RING8[16][2] = {
-  { 8, 0}, { 7, 3}, { 6, 6}, { 3, 7}, { 0, 8}, {-3, 7}, {-6, 6}, {-7, 3},
-  {-8, 0}, {-7,-3}, {-6,-6}, {-3,-7}, { 0,-8}, { 3,-7}, { 6,-6}, { 7,-3}
+ * the cost of the true ones (4-5 iterations each: 42 % of the stage's work) only for a4.3 to reject them.  A radius-11 ring around the
+ * UNREFINED pixel (a Harris maximum sits up to 3 px off its junction on a sharp image, up to 6.5 px under a Gaussian blur of sigma
+ * 2.3: the ring still encloses it) read against its own mid level shows four or more transitions at a junction and two at an
+ * L-corner or an edge.  Candidates that show fewer than four are not refined and reach a4.3 as (-1, -1), which it rejects.  A ring
+ * that leaves the image passes (a5 and a4.3 decide).  Measured over the 12 288 corners of 256 rendered 1080p frames
+ * (scratch/gate_study.py): radius 8 / 9 / 10 / 11 hold back 52 / 17 / 0 / 0 inner corners at sigma 2.0 and 139 / 50 / 1 / 0 at
+ * sigma 2.3; every outline candidate is held back at any of them. */
+static const int8_t RING11[16][2] = {
+  {11, 0}, {10, 4}, { 8, 8}, { 4,10}, { 0,11}, {-4,10}, {-8, 8}, {-10, 4},
+  {-11, 0}, {-10,-4}, {-8,-8}, {-4,-10}, { 0,-11}, { 4,-10}, { 8,-8}, {10,-4}
 };
 int orc_junction_pretest(const uint8_t* grey, int w, int h, int x, int y, int min_contrast)
 {
-  if (x < 8 || y < 8 || x >= w - 8 || y >= h - 8) return 1;
+  if (x < 11 || y < 11 || x >= w - 11 || y >= h - 11) return 1;
   int g[16], lo = 255, hi = 0;
   for (int k = 0; k < 16; ++k) {
-    g[k] = grey[(size_t)(y + RING8[k][1]) * w + (x + RING8[k][0])];
+    g[k] = grey[(size_t)(y + RING11[k][1]) * w + (x + RING11[k][0])];
     if (g[k] < lo) lo = g[k];
     if (g[k] > hi) hi = g[k];
   }

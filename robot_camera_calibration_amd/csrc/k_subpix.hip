@@ -20,11 +20,11 @@
 // per wave costs more in the launch's tail than the ~15 saved loads.)  Tag scenes (FID = true): grid (qstep, nframes) with
 // qstep well below the list's length; a wave walks its frame's list four candidates at a time -- see below and
 // rcc_launch_subpix.
-// a5's gate for board scenes: 16 samples on a radius-8 ring
+// a5's gate for board scenes: 16 samples on a radius-11 ring
 // around the candidate's own pixel against the ring's mid level
-__constant__ int8_t c_ring8[16][2] = {
-  { 8, 0}, { 7, 3}, { 6, 6}, { 3, 7}, { 0, 8}, {-3, 7}, {-6, 6}, {-7, 3},
-  {-8, 0}, {-7,-3}, {-6,-6}, {-3,-7}, { 0,-8}, { 3,-7}, { 6,-6}, { 7,-3}
+__constant__ int8_t c_ring11[16][2] = {
+  {11, 0}, {10, 4}, { 8, 8}, { 4,10}, { 0,11}, {-4,10}, {-8, 8}, {-10, 4},
+  {-11, 0}, {-10,-4}, {-8,-8}, {-4,-10}, { 0,-11}, { 4,-10}, { 8,-8}, {10,-4}
 };
 
 template <bool FID>       // FID: tag scenes (the convex-black-corner test in front of the refinement, waves walk the candidate list)
@@ -41,15 +41,15 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   const uint8_t* g = grey + (size_t)f * w * h;
   if (!FID && fid_min_contrast >= 0) {
     // Board scenes: is the candidate worth refining?  The 36 L-shaped corners on the outline of a 9 x 7-square board took 42 % of
-    // this stage's iterations only to be rejected by a4.3.  Lanes 0..15 read the radius-8 ring around the candidate's pixel (a
-    // Harris maximum sits up to ~3 px off its junction: the ring still encloses it); fewer than four transitions against the
+    // this stage's iterations only to be rejected by a4.3.  Lanes 0..15 read the radius-11 ring around the candidate's pixel (a
+    // Harris maximum sits up to ~3 px off its junction, 6.5 px under heavy blur: the ring still encloses it); fewer than four transitions against the
     // ring's own mid level, or a ring that does not span min_contrast: not a junction -- the wave writes (-1, -1), which a4.3
     // rejects, and retires before it has loaded its tables.  A ring that leaves the image passes.
     const rcc_cand c0 = pre[(size_t)f * kstride + blockIdx.x];
     const int xi = c0.x, yi = c0.y;
-    if (xi >= 8 && yi >= 8 && xi < w - 8 && yi < h - 8) {                         // wave-uniform
+    if (xi >= 11 && yi >= 11 && xi < w - 11 && yi < h - 11) {                         // wave-uniform
       const int k = lane & 15;
-      const int v = (int)g[(size_t)(yi + c_ring8[k][1]) * w + (xi + c_ring8[k][0])];
+      const int v = (int)g[(size_t)(yi + c_ring11[k][1]) * w + (xi + c_ring11[k][0])];
       int lo = v, hi = v;
 #pragma unroll
       for (int off = 1; off < 16; off <<= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }

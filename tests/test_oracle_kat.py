@@ -242,7 +242,7 @@ def test_xjunction_ring_grey(oracle):
 
 
 def test_junction_pretest_gate(oracle):
-    """a5's gate for board scenes (round 4): a radius-8 grey ring around the UNREFINED pixel against its own mid level -- four or
+    """a5's gate for board scenes (round 4): a radius-11 grey ring around the UNREFINED pixel against its own mid level -- four or
     more transitions pass (a junction, also seen from up to 3 px off), fewer do not (an L-corner, a straight edge, a plain area);
     a ring that leaves the image passes; and an independent whole-array derivation on random patches"""
     L = oracle.lib()
@@ -258,7 +258,7 @@ def test_junction_pretest_gate(oracle):
     assert gate(e, 32, 32) == 0 and gate(np.full((64, 64), 128, np.uint8), 32, 32) == 0
     assert gate(lc, 5, 30) == 1 and gate(lc, 32, 60) == 1                       # the ring leaves the image: a5 and a4.3 decide
     ang = 2 * np.pi * np.arange(16) / 16
-    ring = np.stack([np.rint(8.0 * np.cos(ang)), np.rint(8.0 * np.sin(ang))], 1).astype(int)
+    ring = np.stack([np.rint(11.0 * np.cos(ang)), np.rint(11.0 * np.sin(ang))], 1).astype(int)
     for seed in range(80):
         r2 = np.random.default_rng(300 + seed)
         img = _saddle(x0=20 + r2.uniform(-3, 3), y0=20 + r2.uniform(-3, 3), ang=r2.uniform(0, 3), w=40, h=40) if seed % 2 else r2.integers(0, 256, (40, 40)).astype(np.uint8)
