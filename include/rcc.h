@@ -229,8 +229,9 @@ int rcc_rodrigues_m2v_batch(rcc_handle* h, const double* R9, int32_t n, double* 
  * outstanding submission and unpacks its records (same order and contents as rcc_detect_batch).  At most two
  * submissions may be outstanding, so the host can unpack batch k while the device runs batch k+1:
  *     submit(b0); for (k = 1; k < n; ++k) { submit(b_k); collect(&out[k-1]); }  collect(&out[n-1]);
- * `frames` (and `corners`, if given: it is filled by the submission's own copy) must stay valid until that
- * submission has been collected.  RCC_ERR_STATE when called out of order; rcc_detect_batch itself refuses to run
+ * `frames` (and `corners`, if given) must stay valid until that submission has been collected; `corners` is complete when
+ * its collect returns (the tables come over on a copy stream under the next batch's first passes, into a pinned slot of the
+ * handle -- the caller's array may be pageable -- and collect copies them out).  RCC_ERR_STATE when called out of order; rcc_detect_batch itself refuses to run
  * while submissions are outstanding. */
 int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, int32_t frames_mem,
                             rcc_frame_corners* corners, void* stream);

@@ -127,6 +127,7 @@ void rcc_destroy(rcc_handle* h)
   if (h->h_ndet) (void)hipHostFree(h->h_ndet);
   if (h->h_det2) (void)hipHostFree(h->h_det2);
   if (h->h_ndet2) (void)hipHostFree(h->h_ndet2);
+  for (auto& p : h->h_fc) if (p) (void)hipHostFree(p);
   for (auto& ps : h->pstream) if (ps) (void)hipStreamSynchronize(ps);
   for (auto& e : h->sub_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->fc_ready) if (e) (void)hipEventDestroy(e);
@@ -729,9 +730,14 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   HIPCHK(h, hipMemcpyAsync(hn, h->d_ndet, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost, s));
   h->sub_has_fc[slot] = corners ? 1 : 0;
   if (corners) {
+    if (!h->h_fc[slot] && hipHostMalloc((void**)&h->h_fc[slot], sizeof(rcc_frame_corners) * (size_t)h->cfg.batch_capacity) != hipSuccess) {
+      h->h_fc[slot] = nullptr;
+      return RCC_ERR_NOMEM;
+    }
+    h->sub_fc_dst[slot] = corners;
     HIPCHK(h, hipEventRecord(h->fc_ready[slot], s));
     HIPCHK(h, hipStreamWaitEvent(h->pstream[0], h->fc_ready[slot], 0));
-    HIPCHK(h, hipMemcpyAsync(corners, h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, h->pstream[0]));
+    HIPCHK(h, hipMemcpyAsync(h->h_fc[slot], h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, h->pstream[0]));
     HIPCHK(h, hipEventRecord(h->fc_done[slot], h->pstream[0]));
     h->fc_pending = slot + 1;
   }
@@ -755,9 +761,10 @@ int rcc_detect_batch_collect(rcc_handle* h, rcc_detection* det, int32_t* ndet)
   HIPCHK(h, hipSetDevice(h->device));
   const int slot = (int)(h->sub_tail & 1u);
   HIPCHK(h, hipEventSynchronize(h->sub_ev[slot]));
-  if (h->sub_has_fc[slot]) {          // the corner tables came over on the copy stream
+  if (h->sub_has_fc[slot]) {          // the corner tables came over on the copy stream, into the slot's pinned landing area
     HIPCHK(h, hipEventSynchronize(h->fc_done[slot]));
     if (h->fc_pending == slot + 1) h->fc_pending = 0;
+    memcpy(h->sub_fc_dst[slot], h->h_fc[slot], sizeof(rcc_frame_corners) * (size_t)h->sub_nframes[slot]);
   }
   const bool fid = h->cfg.target_kind == RCC_TARGET_FIDUCIAL;
   const int slots = h->cfg.max_targets, nframes = h->sub_nframes[slot];

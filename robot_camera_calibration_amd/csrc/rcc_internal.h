@@ -109,6 +109,9 @@ struct rcc_handle {
   hipEvent_t fc_ready[2], fc_done[2];
   int fc_pending;           // slot + 1 of a corner-table copy the next launch_targets must wait for; 0 none
   unsigned char sub_has_fc[2];
+  rcc_frame_corners* h_fc[2];       // pinned landing areas of those copies (allocated with the first submission that asks for corner tables):
+  rcc_frame_corners* sub_fc_dst[2]; //   the caller's array may be pageable, and a device-to-pageable copy would hold the submitting thread
+                                    //   until the batch is done; rcc_detect_batch_collect copies slot -> caller
   // timing events of the streaming form, a ring over the last RCC_SUBT_RING submissions (submission n uses entry n mod ring, so the
   // previous submission's end is still readable when this one is collected): [0] the stream reaches the batch, [1] ingest done,
   // [2] threshold + corner pass done, [3] list + sub-pixel (+ quads) done, [4] pose done, [5] records in pinned host memory
