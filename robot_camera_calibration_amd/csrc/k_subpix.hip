@@ -31,7 +31,7 @@ template <bool FID>       // FID: tag scenes (the convex-black-corner test in fr
 __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
                                                rcc_subpix_params sp, const rcc_subpix_lane* __restrict__ tab, int kstride,
-                                               double* __restrict__ pre_xy, int fid_min_contrast, int qstep)
+                                               double* __restrict__ pre_xy, int gate_contrast /* min_contrast of the gate in front of the refinement; < 0: no gate (board scenes) */, int qstep)
 {
   __shared__ double S[SP_MAXP * SP_MAXP];
   const int f = blockIdx.y;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   if ((int)blockIdx.x >= np) return;
   const int lane = threadIdx.x;
   const uint8_t* g = grey + (size_t)f * w * h;
-  if (!FID && fid_min_contrast >= 0) {
+  if (!FID && gate_contrast >= 0) {
     // Board scenes: is the candidate worth refining?  The 36 L-shaped corners on the outline of a 9 x 7-square board took 42 % of
     // this stage's iterations only to be rejected by a4.3.  Lanes 0..15 read the radius-11 ring around the candidate's pixel (a
     // Harris maximum sits up to ~3 px off its junction, 6.5 px under heavy blur: the ring still encloses it); fewer than four transitions against the
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
       const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(v > ((lo + hi) >> 1)) & 0xFFFFu;
       const unsigned rotl = ((bits << 1) | (bits >> 15)) & 0xFFFFu;
       const int lo0 = __builtin_amdgcn_readfirstlane(lo), hi0 = __builtin_amdgcn_readfirstlane(hi);
-      if (hi0 - lo0 < fid_min_contrast || __popc(bits ^ rotl) < 4) {
+      if (hi0 - lo0 < gate_contrast || __popc(bits ^ rotl) < 4) {
         if (lane == 0) {
           pre_xy[((size_t)f * kstride + blockIdx.x) * 2] = -1.0;
           pre_xy[((size_t)f * kstride + blockIdx.x) * 2 + 1] = -1.0;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
     const unsigned bits = (unsigned)(wb >> (16 * grp)) & 0xFFFFu;                       // bit k: ring sample k of this group's candidate is white
     const unsigned rotl = ((bits << 1) | (bits >> 15)) & 0xFFFFu;
     const int nblack = 16 - __popc(bits);
-    const bool corner = room && (hi - lo >= fid_min_contrast) && (__popc(bits ^ rotl) == 2) && nblack >= 2 && nblack <= 7;
+    const bool corner = room && (hi - lo >= gate_contrast) && (__popc(bits ^ rotl) == 2) && nblack >= 2 && nblack <= 7;
     if (valid && !corner && (lane & 15) == 0) {
       pre_xy[((size_t)f * kstride + myq) * 2] = (double)xi;
       pre_xy[((size_t)f * kstride + myq) * 2 + 1] = (double)yi;
