@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out/optics_table.json")
     ap.add_argument("--contrasts", default="32,5", help="thr_min_contrast values, each optionally with :harris_thresh (e.g. 32,5,12:3200)")
     ap.add_argument("--workloads", default="board,tags")
+    ap.add_argument("--noise", type=float, default=2.0, help="sensor noise sigma in LSB per channel (rcc_synth_params.noise_sigma)")
     a = ap.parse_args()
     import torch
     from robot_camera_calibration_amd import abi, api, synth
@@ -57,7 +58,7 @@ def main():
             cfg.batch_capacity = n
             cfg.thr_min_contrast = mc
             fam = None
-            sp0 = abi.default_synth_params()
+            sp0 = abi.default_synth_params(noise=a.noise)
             if wl == "tags":
                 fam = abi.load_family()
                 abi.set_fiducial_target(cfg, fam, tag_size=0.10, max_targets=24)
@@ -122,7 +123,7 @@ def main():
                             mism += int(k != len(g) or sorted(int(od[q].id) for q in range(k)) != sorted(int(d.id) for d in g))
                         else:
                             mism += int(k != len(g) or ofc.status != fcs[f].status or ofc.ncorners != fcs[f].ncorners or ofc.nkept != fcs[f].nkept)
-                    row = {"workload": wl, "min_contrast": mc, "harris_thresh": int(cfg.harris_thresh), "blur": bname, "taps": list(sp.blur_taps), "shading": sname,
+                    row = {"workload": wl, "noise_sigma": a.noise, "min_contrast": mc, "harris_thresh": int(cfg.harris_thresh), "blur": bname, "taps": list(sp.blur_taps), "shading": sname,
                            "shade_x_permille": sx, "shade_y_permille": sy, "vignette_permille": vg, "frames": n,
                            "found_rate": float(found_per_frame.mean()), "frames_complete": int((found_per_frame >= 1.0).sum()),
                            "found_rate_by_tilt": {"%d-%d" % b: (float(found_per_frame[(tilts >= b[0]) & (tilts < b[1])].mean()) if ((tilts >= b[0]) & (tilts < b[1])).any() else None) for b in BANDS},

@@ -129,6 +129,25 @@ def test_no_cpu_fallback_without_a_device(built):
     assert e.value.status == abi.RCC_ERR_DEVICE
 
 
+def test_create_refuses_a_host_built_against_another_abi_version(built):
+    """ABI 2 (round 4): rcc_set_record_tables gained an argument in the middle of its list, reserved[0] became tag_refine, the
+    synthetic camera's struct grew and two defaults changed -- a host compiled against the version-1 header must be refused
+    before anything else is looked at (the check runs in front of the device check, so it is testable without a GPU)"""
+    cfg = api.default_config()
+    assert cfg.abi_version == abi.RCC_ABI_VERSION == 2 and built.rcc_abi_version() == 2
+    cfg.abi_version = 1
+    with pytest.raises(api.RccError) as e:
+        api.Detector(cfg)
+    assert e.value.status == abi.RCC_ERR_ARG
+    cfg.abi_version = abi.RCC_ABI_VERSION
+    cfg.pixfmt = 3                                   # beyond RCC_PIX_RGB8
+    with pytest.raises(api.RccError) as e:
+        api.Detector(cfg)
+    assert e.value.status == abi.RCC_ERR_ARG
+    d = api.default_config()
+    assert (d.thr_min_contrast, d.harris_thresh) == (16, 10240)          # the round-4 defaults (BASELINE.md section 4b)
+
+
 def test_product_path_never_imports_the_oracle():
     """only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/"""
     pkg = os.path.join(ROOT, "robot_camera_calibration_amd")

@@ -666,6 +666,41 @@ def test_host_input_pipeline_identical(torch_cuda):
     det.close()
 
 
+def test_streamed_step_times_and_clock_probe(torch_cuda):
+    """the measurement taps bench.py reads (include/rcc_debug.h, round 4): after rcc_detect_batch_collect the device time of that
+    batch, the device's idle time in front of it and the five stage times as they ran inside the streamed step; and the issue probe's
+    clock / cost figures.  Taps only: the records of the streamed batches equal those of the synchronous call."""
+    torch = torch_cuda
+    n = 64
+    cfg = _make(w=1280, h=720, B=n)
+    det = api.Detector(cfg)
+    frames, _ = _render(torch, det, cfg, n, seed=8)
+    torch.cuda.synchronize()
+    d0, f0 = det.detect(frames, n)
+    det.submit(frames, n, want_corners=True); det.submit(frames, n)
+    a, fa = det.collect()
+    st0 = det.last_step_times()
+    det.submit(frames, n)
+    b, _ = det.collect()
+    st1 = det.last_step_times()
+    c, _ = det.collect()
+    st2 = det.last_step_times()
+    assert a.tobytes() == d0.tobytes() and fa.tobytes() == f0.tobytes() and b.tobytes() == d0.tobytes() and c.tobytes() == d0.tobytes()
+    assert st0["idle_before"] == -1.0                                   # the first submission of the handle has no predecessor
+    for st in (st0, st1, st2):
+        stages = [st[k] for k in ("ingest", "dense", "list_subpix_grid", "pnp", "d2h")]
+        assert st["device"] > 0 and all(v >= 0 for v in stages)
+        assert abs(sum(stages) - st["device"]) <= 0.05 * st["device"] + 0.02, st          # the stage events tile the batch
+    assert 0 <= st1["idle_before"] < 5.0 and 0 <= st2["idle_before"] < 5.0
+    ck = det.measure_clock(6, 5.0)
+    assert 800.0 < ck["clock_mhz_min"] <= ck["clock_mhz"] <= ck["clock_mhz_max"] < 3000.0
+    assert 0.5 < ck["ns_per_wave_inst_per_simd"] < 10.0 and 2.0 < ck["cycles_per_wave_inst_per_simd"] < 12.0
+    assert 1.0 < ck["probe_ms"] < 50.0
+    with pytest.raises(api.RccError):
+        det.measure_clock(0, 5.0)
+    det.close()
+
+
 def test_full_size_properties(torch_cuda):
     """1920x1080 (BASELINE.json's size), no oracle: size-independent properties of the path --
     idempotence (same frames twice -> identical records), batch-order independence (a frame's
