@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--tag-refine", default="edges", choices=["edges", "subpix"], help="fiducial corner refinement: refine_edges form (default) or the cornerSubPix form")
     ap.add_argument("--min-contrast", type=int, default=-1, help="cfg.thr_min_contrast (-1: the library's default)")
     ap.add_argument("--harris-thresh", type=int, default=-1, help="cfg.harris_thresh (-1: the library's default)")
+    ap.add_argument("--noise", type=float, default=-1.0, help="synthetic camera: sensor noise sigma in LSB per channel (default: the generator's 2)")
     ap.add_argument("--blur", default="", help="synthetic camera optics: '', '3tap' or a Gaussian sigma in pixels (rcc_synth_params.blur_taps)")
     ap.add_argument("--shade", default="", help="synthetic camera optics: 'gx,gy,vignette' in permille, e.g. 300,-200,400")
     ap.add_argument("--fisheye", action="store_true", help="BASELINE.json configs[3]-style run: fisheye model (use with --width 3840 --height 2160 --batch 256)")
@@ -578,7 +579,7 @@ def main():
     px = a.width * a.height
 
     # ---- workload: B distinct frames per rank, rendered on the device (not timed)
-    sp = abi.default_synth_params()
+    sp = abi.default_synth_params() if a.noise < 0 else abi.default_synth_params(noise=a.noise)
     if a.blur or a.shade:
         sh = [int(v) for v in a.shade.split(",")] if a.shade else [0, 0, 0]
         abi.set_optics(sp, ("3tap" if a.blur == "3tap" else float(a.blur)) if a.blur else None, *sh)
@@ -669,7 +670,7 @@ def main():
                        "frames_per_step_per_gpu": B,
                        "target": ("%dx%d square fiducials of 0.10 m per frame (build family36b), corners by %s, 4-point PnP per tag" % (fid + ("refine_edges" if a.tag_refine == "edges" else "cornerSubPix",))) if fid else "8x6 inner-corner checkerboard, 0.108 m", "distortion": ("fisheye" if a.fisheye else "plumb-bob") + ", undistort on",
                        "detector": {"thr_min_contrast": int(cfg.thr_min_contrast), "harris_thresh": int(cfg.harris_thresh)},
-                       "camera_optics": {"blur_taps": list(sp.blur_taps), "shade_x_permille": int(sp.shade_x_permille), "shade_y_permille": int(sp.shade_y_permille), "vignette_permille": int(sp.vignette_permille)},
+                       "camera_optics": {"noise_sigma": float(sp.noise_sigma), "blur_taps": list(sp.blur_taps), "shade_x_permille": int(sp.shade_x_permille), "shade_y_permille": int(sp.shade_y_permille), "vignette_permille": int(sp.vignette_permille)},
                        "parallelism": "frame-sharded, 1 process per GPU, 1 all_gather of pose records (19 doubles per target slot, packed on the device) per step"},
             "targets_found_in_last_step": int(found), "targets_expected_per_step": int(world * B * tpf), "stage_ms_single_pass": timings, "pipeline_chunks": a.pipeline, "step_form": "sync detect()" if a.sync_steps else "submit/collect, one batch ahead", "value_with_sync_steps": sync_fps,
             "region_order": ["sync detect()" if f else "submit/collect" for f in order], "warmup_form": "the form that is timed (W steps in front of each region)",
