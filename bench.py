@@ -46,6 +46,7 @@ def parse(argv=None):
     ap.add_argument("--ingest-variant", type=int, default=-1)
     ap.add_argument("--roofline-reps", type=int, default=5)
     ap.add_argument("--sync-steps", action="store_true", help="time K synchronous detect() calls instead of the submit/collect stream of K batches")
+    ap.add_argument("--keep-gc", action="store_true", help="A/B: leave Python's cyclic garbage collector running inside the timed regions")
     ap.add_argument("--sync-first", action="store_true", help="A/B of the order: run the synchronous comparison region BEFORE the streamed region that defines `value`")
     ap.add_argument("--pipeline", type=int, default=1, help="chunks of the detector's two-stream pipeline per step (1: single pass)")
     ap.add_argument("--fiducials", default="", help="BASELINE.json configs[4]-style run: GXxGY planar grid of square fiducials per frame, e.g. 6x4")
@@ -130,6 +131,38 @@ def sysfs_clocks(torch, local):
     except Exception:
         pass
     return out
+
+
+class gc_watch:
+    """Python's cyclic garbage collector inside a timed region: every collection that runs is recorded (generation, milliseconds) --
+    a full collection over the heap of a process that has imported torch takes milliseconds, i.e. whole steps.  Unless --keep-gc, the
+    collector is run once and switched off for the region (reference counting still frees what the loop allocates)."""
+    events = []
+    _t0 = None
+
+    @staticmethod
+    def _cb(phase, info):
+        if phase == "start":
+            gc_watch._t0 = time.perf_counter()
+        elif gc_watch._t0 is not None:
+            gc_watch.events.append((int(info.get("generation", -1)), round(1e3 * (time.perf_counter() - gc_watch._t0), 3)))
+
+    def __init__(self, keep):
+        self.keep = keep
+
+    def __enter__(self):
+        import gc
+        if not self.keep:
+            gc.disable()
+        gc_watch.events = []
+        gc.callbacks.append(gc_watch._cb)
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        gc.callbacks.remove(gc_watch._cb)
+        if not self.keep:
+            gc.enable()
 
 
 def host_counters():
@@ -291,7 +324,7 @@ def trace_summary(tr, B, world=1):
         out["device_what"] = "HIP events on the step's stream: device_ms = the stream reaches the batch -> its records are in pinned host memory; device_idle_before = end of the previous batch -> begin of this one: about 0.01 ms while the host keeps one batch ahead (plus the in-line all_gather where ranks exchange records), more where the host submitted late (> 0.1 ms is counted); entry 0 is the start of the region (barrier + synchronize lie in it) and is left out of the two sums"
     if tr.get("host_during_region"):
         out["host_during_region"] = tr["host_during_region"]
-        out["host_during_region_what"] = "rank 0's submitting thread over the K steps: context switches, the cgroup's quota-throttling counters (deltas), the CPU it ran on at both ends"
+        out["host_during_region_what"] = "rank 0's submitting thread over the K steps: context switches, the cgroup's quota-throttling counters (deltas), the CPU it ran on at both ends, and what Python's cyclic garbage collector did (every collection inside the region: generation, ms)"
     st = [x for x in (tr.get("stages") or []) if x and min(x.values()) >= 0]
     if st:
         out["stage_ms_mean"] = {k: sum(x[k] for x in st) / len(st) for k in st[0]}
@@ -605,21 +638,31 @@ def main():
 
     def timed_region(sync_form, want_corners=False):
         """W warm-up steps IN THE FORM THAT IS TIMED (so that the code paths, pinned slots and event rings of that form have all
-        been through once), barrier + synchronize, exactly K steps, synchronize + barrier; max over ranks."""
+        been through once), barrier + synchronize, exactly K steps, synchronize + barrier; max over ranks.  Nothing that takes
+        time may stand between the warm-up and the region: a full garbage collection there (35 ms with torch imported) left the device
+        idle for 39 ms, its clock fell, and the region's first eight steps ran at 3.14, 3.21, 2.97, 2.81 ... ms of DEVICE time instead
+        of 2.65 (`steps_trace.device_idle_before_ms_all[0]` shows the gap).  The collection therefore runs BEFORE the warm-up."""
+        import gc
+        gc.collect()
+        hc0 = host_counters()
         run_steps(det, frames, B, gather, a.warmup, sync_form, want_corners)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         gather.reset_timing()
-        hc0 = host_counters()
-        t0 = time.perf_counter()
-        fnd = run_steps(det, frames, B, gather, a.steps, sync_form, want_corners)
-        tr = run_steps.trace
-        fl = run_steps.local_found
-        torch.cuda.synchronize()
-        dl = time.perf_counter() - t0          # this rank's own K steps, before it waits for the others
+        with gc_watch(a.keep_gc):
+            t0 = time.perf_counter()
+            fnd = run_steps(det, frames, B, gather, a.steps, sync_form, want_corners)
+            tr = run_steps.trace
+            fl = run_steps.local_found
+            torch.cuda.synchronize()
+            dl = time.perf_counter() - t0          # this rank's own K steps, before it waits for the others
+            gcs = list(gc_watch.events)
         hc1 = host_counters()
         tr["host_during_region"] = {k: (hc1[k] - hc0[k]) if k != "cpu" else [hc0[k], hc1[k]] for k in hc1 if k in hc0}
+        tr["host_during_region"]["python_gc"] = "running" if a.keep_gc else "collected before the warm-up, off for the region"
+        tr["host_during_region"]["counters_span"] = "warm-up + region"
+        tr["host_during_region"]["python_gc_collections_generation_ms"] = gcs
         if dist is not None:
             dist.barrier()
         d = time.perf_counter() - t0
