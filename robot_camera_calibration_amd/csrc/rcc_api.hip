@@ -730,10 +730,12 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
   HIPCHK(h, hipMemcpyAsync(hn, h->d_ndet, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost, s));
   h->sub_has_fc[slot] = corners ? 1 : 0;
   if (corners) {
-    if (!h->h_fc[slot] && hipHostMalloc((void**)&h->h_fc[slot], sizeof(rcc_frame_corners) * (size_t)h->cfg.batch_capacity) != hipSuccess) {
-      h->h_fc[slot] = nullptr;
-      return RCC_ERR_NOMEM;
-    }
+    // both landing areas with the first submission that asks for tables (a pinned allocation of 6 MB takes ~7 ms: once, not twice)
+    for (int k = 0; k < 2; ++k)
+      if (!h->h_fc[k] && hipHostMalloc((void**)&h->h_fc[k], sizeof(rcc_frame_corners) * (size_t)h->cfg.batch_capacity) != hipSuccess) {
+        h->h_fc[k] = nullptr;
+        return RCC_ERR_NOMEM;
+      }
     h->sub_fc_dst[slot] = corners;
     HIPCHK(h, hipEventRecord(h->fc_ready[slot], s));
     HIPCHK(h, hipStreamWaitEvent(h->pstream[0], h->fc_ready[slot], 0));
