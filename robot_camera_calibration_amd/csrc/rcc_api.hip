@@ -60,7 +60,7 @@ void rcc_default_config(rcc_config* c)
   c->undistort = 1;
   c->D[0] = -0.28; c->D[1] = 0.07; c->D[2] = 2e-4; c->D[3] = -1e-4; c->D[4] = 0.0;
   // (16, 10240): the pair keeps the flat-tile skip exact (rcc_dense_allow_skip) and finds the board under blur up to sigma 2 px and
-  // 60 % shading (profiles/r04_optics_table.json); rounds 1-3 shipped (32, 200000), tuned on razor-edged renders only
+  // 60 % shading (profiles/r04_b_optics_table.json); rounds 1-3 shipped (32, 200000), tuned on razor-edged renders only
   c->thr_min_contrast = 16;
   c->harris_thresh = 10240;
   c->cand_margin = 8;
@@ -129,6 +129,7 @@ void rcc_destroy(rcc_handle* h)
   if (h->h_ndet2) (void)hipHostFree(h->h_ndet2);
   for (auto& p : h->h_fc) if (p) (void)hipHostFree(p);
   for (auto& ps : h->pstream) if (ps) (void)hipStreamSynchronize(ps);
+  if (h->fc_stream) { (void)hipStreamSynchronize(h->fc_stream); (void)hipStreamDestroy(h->fc_stream); }
   for (auto& e : h->sub_ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->fc_ready) if (e) (void)hipEventDestroy(e);
   for (auto& e : h->fc_done) if (e) (void)hipEventDestroy(e);
@@ -191,6 +192,7 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RCC_ERR_DEVICE; }
   for (auto& e : h->ev) if (hipEventCreate(&e) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   for (auto& ps : h->pstream) if (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
+  if (hipStreamCreateWithFlags(&h->fc_stream, hipStreamNonBlocking) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   for (auto& e : h->pev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rcc_destroy(h); return RCC_ERR_DEVICE; }
   ALLOC(h->d_grey, B * px);
   // d_bin (the full {0,127,255} image, B * px bytes) is allocated on first need (ensure_bin): the default detect path keeps
@@ -738,9 +740,9 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
       }
     h->sub_fc_dst[slot] = corners;
     HIPCHK(h, hipEventRecord(h->fc_ready[slot], s));
-    HIPCHK(h, hipStreamWaitEvent(h->pstream[0], h->fc_ready[slot], 0));
-    HIPCHK(h, hipMemcpyAsync(h->h_fc[slot], h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, h->pstream[0]));
-    HIPCHK(h, hipEventRecord(h->fc_done[slot], h->pstream[0]));
+    HIPCHK(h, hipStreamWaitEvent(h->fc_stream, h->fc_ready[slot], 0));
+    HIPCHK(h, hipMemcpyAsync(h->h_fc[slot], h->d_fc, sizeof(rcc_frame_corners) * (size_t)nframes, hipMemcpyDeviceToHost, h->fc_stream));
+    HIPCHK(h, hipEventRecord(h->fc_done[slot], h->fc_stream));
     h->fc_pending = slot + 1;
   }
   HIPCHK(h, hipEventRecord(tev[5], s));

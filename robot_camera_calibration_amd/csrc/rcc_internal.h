@@ -107,6 +107,7 @@ struct rcc_handle {
   // fc_done[i] = they are in the caller's memory (on the copy stream); the next batch's list stage, the first kernel that writes
   // d_fc again, waits for fc_done
   hipEvent_t fc_ready[2], fc_done[2];
+  hipStream_t fc_stream;    // the copy stream of those tables (its own: the chunk copies of a host-resident batch use pstream[])
   int fc_pending;           // slot + 1 of a corner-table copy the next launch_targets must wait for; 0 none
   unsigned char sub_has_fc[2];
   rcc_frame_corners* h_fc[2];       // pinned landing areas of those copies (allocated with the first submission that asks for corner tables):

@@ -291,3 +291,14 @@ print("ok")
 '''
     out = subprocess.run([sys.executable, "-c", child, os.path.join(ROOT, "robot_camera_calibration_amd", "librcc_tagmap.so")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+
+
+def test_ros_shim_node_compiles_against_stand_in_headers():
+    """N3: host/tag_detections_shim.cpp has never met a compiler (no ROS in the image).  `g++ -fsyntax-only -Wall -Wextra` over the
+    node with minimal stand-ins for the roscpp / sensor_msgs / apriltag_ros declarations it uses (tests/host/mock_ros/): its own
+    code is well-formed C++ against the shapes of the API it calls -- it proves nothing about roscpp itself."""
+    src = os.path.join(ROOT, "robot_camera_calibration_amd", "host", "tag_detections_shim.cpp")
+    r = subprocess.run(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "tests", "host", "mock_ros"),
+                        "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "robot_camera_calibration_amd", "host"), src],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]
