@@ -757,7 +757,7 @@ def main():
             if os.path.exists(tpath) and (a.width, a.height) == (1920, 1080) and not a.fisheye:
                 try:
                     j = json.load(open(tpath))
-                    return j.get("hbm_bytes_per_frame") * B, "profiles/%s <- profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of %s on an earlier run of this code (another box), scaled per frame; not measured in this run" % (name, j.get("source"), j.get("kernel"))
+                    return j.get("hbm_bytes_per_frame") * B, "profiles/%s <- profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of %s, taken on the %s (another box), scaled per frame; not measured in this run" % (name, j.get("source"), j.get("kernel"), j.get("code", "code of an earlier run"))
                 except Exception:
                     pass
             return None, "none"
@@ -789,7 +789,7 @@ def main():
                 return {"valu_wave_insts_per_frame": valu, "salu_wave_insts_per_frame": salu, "ns_per_inst": ns_inst, "cycles_per_inst": cyc,
                         "cycles_per_inst_source": cost_src,
                         "simds": simds, "clock_mhz": clock_mhz, "clock_source": clock_src, "issue_bound_ms": bound_ms, "frac_of_issue_bound": bound_ms / ms_launch,
-                        "source": "profiles/%s <- profiles/%s: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU of %s on an earlier run of this code, scaled per frame; not measured in this run" % (name, j.get("source"), j.get("kernel"))}
+                        "source": "profiles/%s <- profiles/%s: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU of %s, taken on the %s, scaled per frame; not measured in this run" % (name, j.get("source"), j.get("kernel"), j.get("code", "code of an earlier run"))}
             except Exception:
                 return None
         tr_c, src_c = traffic_of("traffic_dense_step.json")
