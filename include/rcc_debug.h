@@ -30,8 +30,9 @@ extern "C" {
  * per window where the binary image is kept as the compact map, the band kernel otherwise (k_dense_wave.hip);
  * -1 = automatic (4 where the geometry allows it, else 2, else 0) */
 int rcc_set_dense_variant(rcc_handle* h, int variant);
-/* undistort + grey pass: 0 = gather (any geometry), 1 = LDS-staged tiles with the tabulated map (128 x 16 destination tiles), 2 = staged, map recomputed per block (128 x 8 tiles), 3 = staged, tabulated
- * map, 128 x 8 tiles; -1 = automatic */
+/* undistort + grey pass: 0 = gather (any geometry), 1 = LDS-staged 128 x 16 destination tiles with the tabulated map, 2 = staged,
+ * map recomputed per block (the form a handle falls back to when the table cannot be allocated), 3 = staged with the 128 x 8 tiles
+ * of rounds 1-3 (experiments library only: the product library runs 1 in its place); -1 = automatic */
 int rcc_set_ingest_variant(rcc_handle* h, int variant);
 /* 1 (default): the marching dense kernels skip the corner stages on wave-rows whose tiles are all flat (exact); 0: never */
 int rcc_set_dense_skip(rcc_handle* h, int on);

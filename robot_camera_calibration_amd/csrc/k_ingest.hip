@@ -185,7 +185,7 @@ hipError_t rcc_ingest_staged_plan(rcc_handle* h, const uint8_t* d_frames, int nf
   *staged = false;
   if (!h->undist || nframes <= 0) return hipSuccess;
   int variant = h->ingest_variant;
-  const bool staged_ok = ((w % ST_TW) == 0) && ((ht % ST_TH) == 0) && ((c.stride_bytes & 15) == 0) && ((c.frame_bytes & 15) == 0) &&
+  const bool staged_ok = ((w % ST_TW) == 0) && ((ht % ST_TH) == 0) && ht >= 16 && ((c.stride_bytes & 15) == 0) && ((c.frame_bytes & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0);
   if (variant < 0) variant = staged_ok ? 1 : 0;
   if (variant != 1 || !staged_ok) return hipSuccess;
@@ -193,11 +193,13 @@ hipError_t rcc_ingest_staged_plan(rcc_handle* h, const uint8_t* d_frames, int nf
   // tile height: 16 rows (1.16 instead of 1.25 source rows per destination row; measured on 256 x 4K fisheye: 1.735 -> 1.589 ms),
   // unless the 8-row form is asked for (rcc_set_ingest_variant(3): A/B, tests)
 #ifdef RCC_EXPERIMENTS
+  // the experiments library also carries the 128 x 8 form (rcc_set_ingest_variant(3), RCC_INGEST_TH=8: rounds 1-3, the A/B partner)
+  // and a 128 x 32 form (RCC_INGEST_TH=32: measured, not kept)
   static const int th_env = getenv("RCC_INGEST_TH") ? atoi(getenv("RCC_INGEST_TH")) : 0;
+  const int TH = (h->ingest_tile8 || th_env == 8) ? ST_TH : (th_env == 32 && ht >= 32) ? 32 : 16;
 #else
-  const int th_env = 0;
-#endif
-  const int TH = h->ingest_tile8 ? ST_TH : (th_env == 32 && ht >= 32) ? 32 : (ht >= 16 && th_env != 8) ? 16 : ST_TH;       // (a height of 8 mod 16: the last tile row's lower half is idle)
+  const int TH = 16;
+#endif       // (a height of 8 mod 16: the last tile row's lower half is idle)
   p->th = TH;
 #ifdef RCC_EXPERIMENTS
   static const int fpb_max = getenv("RCC_INGEST_FPB") ? atoi(getenv("RCC_INGEST_FPB")) : 32;
@@ -218,9 +220,12 @@ hipError_t rcc_ingest_staged_plan(rcc_handle* h, const uint8_t* d_frames, int nf
       h->d_map = nullptr; h->d_tilebox = nullptr; h->map_failed = 1;      // no room: the kernel recomputes the map itself
       (void)hipGetLastError();
     } else {
+#ifdef RCC_EXPERIMENTS
       if (TH == 32) hipLaunchKernelGGL(k_ingest_map<32>, dim3(tiles), dim3(1024), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
-      else if (TH == 16) hipLaunchKernelGGL(k_ingest_map<16>, dim3(tiles), dim3(512), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
-      else hipLaunchKernelGGL(k_ingest_map<ST_TH>, dim3(tiles), dim3(256), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
+      else if (TH == ST_TH) hipLaunchKernelGGL(k_ingest_map<ST_TH>, dim3(tiles), dim3(256), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
+      else
+#endif
+      hipLaunchKernelGGL(k_ingest_map<16>, dim3(tiles), dim3(512), 0, s, w, ht, p->cam, p->ntx, (int2*)h->d_map, (int4*)h->d_tilebox);
       hipError_t em = hipGetLastError();
       if (em == hipSuccess) em = hipStreamSynchronize(s);      // once per handle: later launches may come on other streams
       if (em != hipSuccess) {
@@ -280,16 +285,16 @@ hipError_t rcc_launch_ingest(rcc_handle* h, const uint8_t* d_frames, int nframes
         if (c.pixfmt == RCC_PIX_RGB8) LAUNCH_STAGED(3, true, 32);
         else if (c.pixfmt == RCC_PIX_BGR8) LAUNCH_STAGED(3, false, 32);
         else LAUNCH_STAGED(1, false, 32);
-      } else
-#endif
-      if (p.th == 16) {
-        if (c.pixfmt == RCC_PIX_RGB8) LAUNCH_STAGED(3, true, 16);
-        else if (c.pixfmt == RCC_PIX_BGR8) LAUNCH_STAGED(3, false, 16);
-        else LAUNCH_STAGED(1, false, 16);
-      } else {
+      } else if (p.th == ST_TH) {
         if (c.pixfmt == RCC_PIX_RGB8) LAUNCH_STAGED(3, true, ST_TH);
         else if (c.pixfmt == RCC_PIX_BGR8) LAUNCH_STAGED(3, false, ST_TH);
         else LAUNCH_STAGED(1, false, ST_TH);
+      } else
+#endif
+      {
+        if (c.pixfmt == RCC_PIX_RGB8) LAUNCH_STAGED(3, true, 16);
+        else if (c.pixfmt == RCC_PIX_BGR8) LAUNCH_STAGED(3, false, 16);
+        else LAUNCH_STAGED(1, false, 16);
       }
 #undef LAUNCH_STAGED
       return hipGetLastError();

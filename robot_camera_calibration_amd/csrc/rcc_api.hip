@@ -329,8 +329,9 @@ int rcc_set_pnp_mfma(rcc_handle* h, int on)
   h->pnp_use_mfma = on ? 1 : 0;
   return p;
 }
-// variant: 0 gather, 1 staged with the tabulated map (default where the geometry allows: 128 x 16 tiles), 2 staged recomputing the map per block (128 x 8 tiles), 3 staged with the tabulated map and
-// 128 x 8 tiles; -1 automatic
+// variant: 0 gather, 1 staged with the tabulated map (default where the geometry allows; 128 x 16 destination tiles), 2 staged
+// recomputing the map per block (the form a handle falls back to when the table cannot be allocated), 3 staged with the tabulated
+// map and the 128 x 8 tiles of rounds 1-3 (experiments library only; the product library runs 1 in its place); -1 automatic
 int rcc_set_ingest_variant(rcc_handle* h, int variant)
 {
   if (!h) return RCC_ERR_ARG;
@@ -338,7 +339,7 @@ int rcc_set_ingest_variant(rcc_handle* h, int variant)
   if (p == 1 && !h->ingest_table) p = 2;
   else if (p == 1 && h->ingest_tile8) p = 3;
   h->ingest_table = (variant == 2) ? 0 : 1;
-  h->ingest_tile8 = (variant == 2 || variant == 3) ? 1 : 0;
+  h->ingest_tile8 = (variant == 3) ? 1 : 0;
   h->ingest_variant = (variant == 2 || variant == 3) ? 1 : variant;
   return p;
 }

@@ -59,7 +59,7 @@ while time.time() - t0 < budget:
         f1 = torch.randint(0, 256, (n, padded.frame_bytes), dtype=torch.uint8, device="cuda:0")
         f1[:, :stride * h].view(n, h, stride)[:, :, :w * ch] = f0.view(n, h, w * ch)
         d1 = api.Detector(padded)
-        sw = dict(dense=int(rng.choice([-1, 0, 1, 2, 3, 4])), skip=int(rng.integers(2)), gang=int(rng.choice([0, 0, 1, 4, 16])) if EXP else 0, ingest=int(rng.choice([-1, 0, 1, 2, 3])),
+        sw = dict(dense=int(rng.choice([-1, 0, 1, 2, 3, 4])), skip=int(rng.integers(2)), gang=int(rng.choice([0, 0, 1, 4, 16])) if EXP else 0, ingest=int(rng.choice([-1, 0, 1, 2, 3] if EXP else [-1, 0, 1, 2])),
                   fuse=int(rng.integers(2)), pipe=int(rng.choice([0, 0, 2, 3])), pnp=int(rng.choice([-1, 1])), keep=int(rng.integers(2)), grid=int(rng.choice([0, 1, 5, 64])))
         d1.set_dense_variant(sw["dense"]); d1.set_dense_skip(sw["skip"]); d1.set_ingest_variant(sw["ingest"])
         if EXP: d1.set_dense_gang(sw["gang"])

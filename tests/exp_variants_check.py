@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Helper of tests/test_experiments_library.py (not a test module): runs in a child process whose RCC_LIBRARY points at
 librcc_hip_exp.so and checks the measurement-only forms of the threshold + corner pass that only that library carries --
-the two-kernel variant 3 (band sweep + k_dense_runs on the active rows) and the gang form of k_dense_wave -- for bit-identity
+the two-kernel variant 3 (band sweep + k_dense_runs on the active rows), the gang form of k_dense_wave and the 128 x 8 ingest
+tiles of rounds 1-3 -- for bit-identity
 with the forms the product library runs.  Prints one digest per geometry of the default form's outputs; the parent compares
 them with the product library's on the same frames."""
 import hashlib
@@ -28,25 +29,28 @@ def digest_default(torch, abi, api, synth, kind, w, h, n, exp):
     det.synth_render(sp, poses, frames)
     px = w * h
 
-    def stage(dv, skip):
-        det.set_dense_variant(dv); det.set_dense_skip(skip)
+    def stage(dv, skip, iv=-1):
+        det.set_dense_variant(dv); det.set_dense_skip(skip); det.set_ingest_variant(iv)
         grey = torch.zeros((n, px), dtype=torch.uint8, device="cuda:0"); binm = torch.zeros((n, px), dtype=torch.uint8, device="cuda:0")
         cand = torch.zeros((n, cfg.max_candidates * 8), dtype=torch.uint8, device="cuda:0"); cnt = torch.zeros((n,), dtype=torch.int32, device="cuda:0")
         torch.cuda.synchronize()
         det.stage_ingest(frames, n, grey)
         det.stage_threshold_corner(grey, n, binm, cand, cnt)
         c = cand.cpu().numpy().view(api.CAND_DT).reshape(n, cfg.max_candidates); k = cnt.cpu().numpy()
-        return binm.cpu().numpy(), [sorted_cands(c[f][:k[f]]) for f in range(n)], k, det.last_dense_kernel()
+        return binm.cpu().numpy(), [sorted_cands(c[f][:k[f]]) for f in range(n)], k, det.last_dense_kernel(), grey.cpu().numpy()
     ref = stage(-1, 1)
     det.set_dense_variant(-1); det.set_dense_skip(1)
     d0, f0 = det.detect(frames, n)
     img0 = det.fetch_images(n)
     hsh = hashlib.sha256()
-    for a in (ref[0], ref[2], d0, f0, img0["bin"], img0["cand_count"]):
+    for a in (ref[0], ref[2], ref[4], d0, f0, img0["bin"], img0["cand_count"]):
         hsh.update(np.ascontiguousarray(a).tobytes())
     for c in ref[1]:
         hsh.update(np.ascontiguousarray(c).tobytes())
     if exp:
+        o = stage(-1, 1, 3)                                 # the 128 x 8 ingest tiles of rounds 1-3 (the product runs 128 x 16)
+        assert (o[4] == ref[4]).all() and (o[0] == ref[0]).all(), "ingest variant 3: grey / binary image differ at %dx%d" % (w, h)
+        det.set_ingest_variant(-1)
         for dv, skip in ((3, 1), (3, 0)):                  # the two-kernel form, through the stage call and through detect()
             o = stage(dv, skip)
             assert "k_dense_runs" in o[3], o[3]
