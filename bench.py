@@ -822,6 +822,12 @@ def main():
         out["roofline_ingest"] = {"bound": "hbm", "kernel": "k_ingest_staged<3> (undistort + grey)", "achieved": algi / (msi * 1e-3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algi / (msi * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "traffic": tr_i, "traffic_source": src_i, "alg_bytes_per_launch": algi, "ms_per_launch": msi}
+        # the whole step against HBM: SURVEY 8(d)'s algorithmic bytes of the three passes over pixels (ingest 4 px, threshold + corner
+        # pass px + px / 16 as the step runs it; the tail's bytes are negligible) over the step's time
+        alg_step = (4.0 + 1.0 + 1.0 / 16.0) * px * B
+        out["roofline_step"] = {"what": "all passes of one step: algorithmic bytes (ingest 4 px + threshold/corner pass (1 + 1/16) px per frame) / ms_per_step; the step also holds the issue-bound corner arithmetic and the latency-bound tail, so this is a lower bound on how well the two streaming passes use HBM",
+                                "alg_bytes_per_step": alg_step, "achieved": alg_step / (1e-3 * out["ms_per_step"]) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": alg_step / (1e-3 * out["ms_per_step"]) / 1e9 / HBM_PEAK_GBS}
         del grey, binm, cand, cnt
 
     # ---- the two other rates SURVEY.md 8(d) asks for (rank 0, N=1): frames handed over in HOST memory (PCIe inside
