@@ -116,7 +116,10 @@ typedef struct rcc_config {
   int32_t xj_check;         /* 1: board scenes keep only X-junctions: a5 refines only candidates whose radius-11 grey ring shows >= 4
                                transitions, a4.3 validates on two radius-5 rings at the refined pixel; 0: every
                                suppressed candidate is refined and kept */
-  int32_t max_kept;         /* per-frame capacity after suppression + validation (<= 256) */
+  int32_t max_kept;         /* board scenes: per-frame capacity of the VALIDATED list (entries that pass a4.3's ring tests; <= 256); the
+                               list after suppression holds up to 2048 entries (ABI 1: this value bounded both, so ~100 objects in
+                               view rejected the frame); tag scenes: capacity of the list after suppression (<= 2048).  More:
+                               RCC_FRAME_KEPT_OVERFLOW, the frame yields nothing */
 
   /* a5 sub-pixel refinement (cornerSubPix form) */
   int32_t subpix_win;       /* half window w: (2w+1)^2 samples; 1..7 */

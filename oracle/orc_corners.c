@@ -22,7 +22,7 @@
  * host libm (the product library does the same on the host and uploads the table).
  * ---------------------------------------------------------------------------------------------- */
 #define SP_MAXW 7
-#define GMAXPTS_V 256
+#define GMAXPTS_V 2048        /* entries of the suppressed list a4.3 looks at (RCC_MAX_KEPT_FIDUCIAL) */
 
 static double tree64(double* v)
 {
@@ -131,7 +131,8 @@ void orc_corner_subpix(const uint8_t* g, int w, int h, const orc_cand* pts, int 
  *   - de-duplication: drop i if another validated j lies within Chebyshev distance dedupe_radius
  *     of it and has a larger score (or an equal score and a smaller index).  Not greedy.
  * Output keeps the input order; out[k].x/.y are the rounded refined pixel, out_xy the refined
- * position.  Returns the number kept (may exceed cap; only cap are written).
+ * position.  Returns the number kept, or a number > cap when more than cap entries pass the ring tests (nothing usable is
+ * written then).
  * ---------------------------------------------------------------------------------------------- */
 int orc_validate_refined(const orc_cand* pre, int n, const double* xy, const uint8_t* bin, const uint8_t* grey, int w,
                          int h, int xj_check, int min_contrast, int dedupe_radius, orc_cand* out, double* out_xy, int cap)
@@ -145,6 +146,13 @@ int orc_validate_refined(const orc_cand* pre, int n, const double* xy, const uin
     int v = (x >= 5 && y >= 5 && x < w - 5 && y < h - 5);
     if (v && xj_check) v = orc_xjunction_ring(bin, w, h, x, y) && orc_xjunction_ring_grey(grey, w, h, x, y, min_contrast);
     ok[i] = (uint8_t)v;
+  }
+  /* capacity [B]: at most `cap` entries may pass the ring tests (what the lattice stage is built for); more -- a cluttered scene full
+   * of junction-like points -- and the frame is rejected by the caller (the count returned exceeds cap) */
+  {
+    int nvalid = 0;
+    for (int i = 0; i < n; ++i) nvalid += ok[i];
+    if (nvalid > cap) return nvalid;
   }
   int m = 0;
   for (int i = 0; i < n; ++i) {

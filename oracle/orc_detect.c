@@ -77,8 +77,13 @@ int orc_ctx_detect(orc_ctx* c, const uint8_t* frame, int frame_index, rcc_detect
   rcc_frame_corners fcl;
   rcc_frame_corners* fc = fc_out ? fc_out : &fcl;
   memset(fc, 0, sizeof(*fc));
-  const int kept_lim = (cfg->target_kind == RCC_TARGET_FIDUCIAL) ? RCC_MAX_KEPT_FIDUCIAL : 256;
-  const int max_kept = cfg->max_kept < kept_lim ? cfg->max_kept : kept_lim;
+  /* capacities [B].  The list after suppression (a4.2) holds up to RCC_MAX_KEPT_FIDUCIAL = 2048 entries for every target kind (tag
+   * scenes: cfg->max_kept of them at most); for the board cfg->max_kept (<= 256, what the lattice stage is built for) bounds the
+   * VALIDATED list of a4.3 only -- since round 4: a5's gate drops what cannot be a junction before it costs anything, so a cluttered
+   * scene may bring hundreds of suppressed candidates (rounds 1-3 rejected the frame beyond 256). */
+  const int fidt = (cfg->target_kind == RCC_TARGET_FIDUCIAL);
+  const int max_pre = fidt ? (cfg->max_kept < RCC_MAX_KEPT_FIDUCIAL ? cfg->max_kept : RCC_MAX_KEPT_FIDUCIAL) : RCC_MAX_KEPT_FIDUCIAL;
+  const int max_kept = fidt ? max_pre : (cfg->max_kept < 256 ? cfg->max_kept : 256);
 
   ingest(c, frame);
   orc_threshold_tiles(c->grey, w, h, cfg->thr_min_contrast, c->bin);
@@ -94,9 +99,9 @@ int orc_ctx_detect(orc_ctx* c, const uint8_t* frame, int frame_index, rcc_detect
   if (ncand > cfg->max_candidates) { fc->status = RCC_FRAME_CAND_OVERFLOW; return 0; }
 
   /* a4.2 list-level suppression (no ring test yet), a5 refine every survivor, a4.3 validate */
-  int npre = orc_filter_candidates(c->cand, ncand, c->bin, w, h, cfg->nms_radius, 0, c->pre, max_kept);
-  if (npre_out) *npre_out = npre;
-  if (npre > max_kept) { fc->status = RCC_FRAME_KEPT_OVERFLOW; return 0; }
+  int npre = orc_filter_candidates(c->cand, ncand, c->bin, w, h, cfg->nms_radius, 0, c->pre, max_pre);
+  if (npre_out) *npre_out = npre > max_pre ? 0 : npre;
+  if (npre > max_pre) { fc->status = RCC_FRAME_KEPT_OVERFLOW; return 0; }
   if (pre_out) memcpy(pre_out, c->pre, sizeof(orc_cand) * (size_t)npre);
   double* pxy = c->pxy;
   double xy[2 * 256];
@@ -160,6 +165,7 @@ int orc_ctx_detect(orc_ctx* c, const uint8_t* frame, int frame_index, rcc_detect
     return m;
   }
   int nkept = orc_validate_refined(c->pre, npre, pxy, c->bin, c->grey, w, h, cfg->xj_check, cfg->thr_min_contrast, 2, c->kept, xy, max_kept);
+  if (nkept > max_kept) { fc->status = RCC_FRAME_KEPT_OVERFLOW; return 0; }       /* more validated points than the lattice stage takes */
   fc->nkept = nkept;
   if (nkept_out) *nkept_out = nkept;
   if (kept_out) memcpy(kept_out, c->kept, sizeof(orc_cand) * (size_t)nkept);

@@ -456,7 +456,7 @@ class Detector:
 
     # ---- test taps ---------------------------------------------------------------------------------
     def fetch_lists(self, nframes):
-        kc = abi.RCC_MAX_KEPT_FIDUCIAL if self.cfg.target_kind == abi.RCC_TARGET_FIDUCIAL else 256
+        kc = abi.RCC_MAX_KEPT_FIDUCIAL          # capacity of the list after suppression, whatever the target (round 4)
         pre = np.zeros((nframes, kc), CAND_DT); kept = np.zeros((nframes, 256), CAND_DT)
         npre = np.zeros(nframes, np.int32)
         pre_xy = np.zeros((nframes, kc, 2)); kept_xy = np.zeros((nframes, 256, 2))

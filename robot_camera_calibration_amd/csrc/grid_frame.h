@@ -176,11 +176,14 @@ __device__ __forceinline__ int nearest_free(const int (&pxr)[J], const int (&pyr
   return (int)(b & 255ull);
 }
 
-// ---- a4.3: validation of the refined corners of frame f, NT threads (one candidate per thread and pass): ring test at the
-// rounded refined position, de-duplication, ordered compaction into the frame's kept lists (global) + fc[f].nkept
+// ---- a4.3: validation of the refined corners of frame f, NT threads (one candidate per thread and pass): ring tests at the
+// rounded refined position, de-duplication among the entries that pass, ordered compaction into the frame's kept lists (global) +
+// fc[f].nkept.  The suppressed list may hold up to `pre_stride` (2048) entries -- a cluttered scene -- of which at most `max_kept`
+// (<= 256, what the lattice stage is built for) may pass the ring tests: more, and the frame is rejected (RCC_FRAME_KEPT_OVERFLOW).
 struct valid_smem {
-  int32_t score[RCC_MAX_KEPT];
-  uint32_t pos[RCC_MAX_KEPT];      // packed rounded refined pixel x | y << 16 of list entry i; GRID_NOPOS where it failed the ring test
+  int32_t score[RCC_MAX_KEPT];     // of the entries that passed the ring tests, in list order
+  uint32_t pos[RCC_MAX_KEPT];      // their packed rounded refined pixel x | y << 16
+  uint16_t src[RCC_MAX_KEPT];      // their index in the suppressed list
   uint8_t keep[RCC_MAX_KEPT];
   int32_t wcnt[4];
 };
@@ -189,7 +192,7 @@ __device__ __forceinline__ void validate_frame(valid_smem& sm, const int f, cons
                                                const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
                                                const uint8_t* __restrict__ thr, int nbands, int w, int h,
                                                const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                               const double* __restrict__ pre_xy, int xj_check, int min_contrast, int dedupe_radius,
+                                               const double* __restrict__ pre_xy, int pre_stride, int max_kept, int xj_check, int min_contrast, int dedupe_radius,
                                                rcc_frame_corners* __restrict__ fc,
                                                rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out)
 {
@@ -203,39 +206,66 @@ __device__ __forceinline__ void validate_frame(valid_smem& sm, const int f, cons
   b.thr = thr ? thr + (size_t)f * nbands * (h >> 2) * RCC_THR_PITCH : nullptr;
   b.w = w; b.th = h >> 2;
   const int n = npre[f];
+  if (max_kept > RCC_MAX_KEPT) max_kept = RCC_MAX_KEPT;
 
-  for (int i = tid; i < n; i += NT) {
-    const double x = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2], y = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2 + 1];
-    const int xi = (int)floor(x + 0.5), yi = (int)floor(y + 0.5);
-    sm.score[i] = pre[(size_t)f * RCC_MAX_KEPT + i].score;
-    bool v = (xi >= 5 && yi >= 5 && xi < w - 5 && yi < h - 5);
-    if (v && xj_check) v = ring_ok(b, w, h, xi, yi, min_contrast);
-    sm.pos[i] = v ? ((unsigned)xi | ((unsigned)yi << 16)) : GRID_NOPOS;
-  }
-  __syncthreads();
-  // de-duplication: entry i goes if a valid entry within +-dedupe_radius has a larger score (or the same score and a smaller
-  // index).  An entry that failed the ring test sits at GRID_NOPOS, out of every valid entry's reach.  Branch-free and
-  // unrolled (an early exit made every iteration wait for its own LDS round trip).
-  for (int i = tid; i < n; i += NT) {
-    const unsigned pi = sm.pos[i];
-    const int xi = (int)(pi & 0xFFFFu), yi = (int)(pi >> 16), si = sm.score[i];
-    bool keep = pi != GRID_NOPOS;
-#pragma unroll 8
-    for (int j = 0; j < n; ++j) {
-      const unsigned pj = sm.pos[j];
-      const int sj = sm.score[j];
-      const int dx = abs((int)(pj & 0xFFFFu) - xi), dy = abs((int)(pj >> 16) - yi);
-      const bool beats = (j != i) && (dx <= dedupe_radius) && (dy <= dedupe_radius) && (sj > si || (sj == si && j < i));
-      keep = keep && !beats;
-    }
-    sm.keep[i] = keep ? 1 : 0;
-  }
-  __syncthreads();
-  // ordered compaction
+  // ring tests, and the entries that pass gathered in list order (ballot + per-wave counts)
   int m = 0;
   for (int base = 0; base < n; base += NT) {
     const int i = base + tid;
-    const bool k = (i < n) && sm.keep[i];
+    bool v = false;
+    int xi = 0, yi = 0;
+    if (i < n) {
+      const double x = pre_xy[((size_t)f * pre_stride + i) * 2], y = pre_xy[((size_t)f * pre_stride + i) * 2 + 1];
+      xi = (int)floor(x + 0.5); yi = (int)floor(y + 0.5);
+      v = (xi >= 5 && yi >= 5 && xi < w - 5 && yi < h - 5);
+      if (v && xj_check) v = ring_ok(b, w, h, xi, yi, min_contrast);
+    }
+    const unsigned long long bal = __ballot(v);
+    int before = 0, total = __popcll(bal);
+    if (NT > 64) {
+      if (lane == 0) sm.wcnt[wv] = total;
+      __syncthreads();
+      total = 0;
+#pragma unroll
+      for (int q = 0; q < NT / 64; ++q) { const int c = sm.wcnt[q]; before += (q < wv) ? c : 0; total += c; }
+    }
+    if (m + total > max_kept) {          // block-uniform: more validated points than the lattice stage takes
+      if (tid == 0) { out->status = RCC_FRAME_KEPT_OVERFLOW; out->nkept = 0; }
+      return;
+    }
+    if (v) {
+      const int o = m + before + __popcll(bal & ((1ull << lane) - 1ull));
+      sm.pos[o] = (unsigned)xi | ((unsigned)yi << 16);
+      sm.score[o] = pre[(size_t)f * pre_stride + i].score;
+      sm.src[o] = (uint16_t)i;
+    }
+    m += total;
+    if (NT > 64) __syncthreads();        // wcnt is rewritten by the next pass
+  }
+  __syncthreads();
+  // de-duplication among the m entries that passed: entry a goes if another within +-dedupe_radius has a larger score (or the same
+  // score and a smaller index -- the gathered order is the list's).  Branch-free and unrolled (an early exit made every iteration
+  // wait for its own LDS round trip).
+  for (int a = tid; a < m; a += NT) {
+    const unsigned pa = sm.pos[a];
+    const int xa = (int)(pa & 0xFFFFu), ya = (int)(pa >> 16), sa = sm.score[a];
+    bool keep = true;
+#pragma unroll 8
+    for (int j = 0; j < m; ++j) {
+      const unsigned pj = sm.pos[j];
+      const int sj = sm.score[j];
+      const int dx = abs((int)(pj & 0xFFFFu) - xa), dy = abs((int)(pj >> 16) - ya);
+      const bool beats = (j != a) && (dx <= dedupe_radius) && (dy <= dedupe_radius) && (sj > sa || (sj == sa && j < a));
+      keep = keep && !beats;
+    }
+    sm.keep[a] = keep ? 1 : 0;
+  }
+  __syncthreads();
+  // ordered compaction
+  int kout = 0;
+  for (int base = 0; base < m; base += NT) {
+    const int a = base + tid;
+    const bool k = (a < m) && sm.keep[a];
     const unsigned long long bal = __ballot(k);
     int before = 0, total = __popcll(bal);
     if (NT > 64) {
@@ -246,18 +276,19 @@ __device__ __forceinline__ void validate_frame(valid_smem& sm, const int f, cons
       for (int q = 0; q < NT / 64; ++q) { const int c = sm.wcnt[q]; before += (q < wv) ? c : 0; total += c; }
     }
     if (k) {
-      const int o = m + before + __popcll(bal & ((1ull << lane) - 1ull));
-      const unsigned pi = sm.pos[i];
+      const int o = kout + before + __popcll(bal & ((1ull << lane) - 1ull));
+      const unsigned pa = sm.pos[a];
+      const int i = sm.src[a];
       rcc_cand e;
-      e.x = (int16_t)(pi & 0xFFFFu); e.y = (int16_t)(pi >> 16); e.score = sm.score[i];
+      e.x = (int16_t)(pa & 0xFFFFu); e.y = (int16_t)(pa >> 16); e.score = sm.score[a];
       kept_out[(size_t)f * RCC_MAX_KEPT + o] = e;
-      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2] = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2];
-      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2 + 1] = pre_xy[((size_t)f * RCC_MAX_KEPT + i) * 2 + 1];
+      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2] = pre_xy[((size_t)f * pre_stride + i) * 2];
+      kept_xy_out[((size_t)f * RCC_MAX_KEPT + o) * 2 + 1] = pre_xy[((size_t)f * pre_stride + i) * 2 + 1];
     }
-    m += total;
+    kout += total;
     if (NT > 64) __syncthreads();        // wcnt is rewritten by the next pass
   }
-  if (tid == 0) out->nkept = m;
+  if (tid == 0) out->nkept = kout;
 }
 
 // ---- a6: board indexing of frame f from its kept lists (validate_frame's output), ONE wavefront.  Returns true when the

@@ -14,12 +14,12 @@
 __global__ __launch_bounds__(256) void k_validate(const uint8_t* __restrict__ bin, const uint8_t* __restrict__ grey,
                                                  const uint8_t* __restrict__ thr, int nbands, int w, int h,
                                                  const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                                 const double* __restrict__ pre_xy, int xj_check, int min_contrast, int dedupe_radius,
+                                                 const double* __restrict__ pre_xy, int pre_stride, int max_kept, int xj_check, int min_contrast, int dedupe_radius,
                                                  rcc_frame_corners* __restrict__ fc,
                                                  rcc_cand* __restrict__ kept_out, double* __restrict__ kept_xy_out)
 {
   __shared__ valid_smem sm;
-  validate_frame<256>(sm, blockIdx.x, threadIdx.x, bin, grey, thr, nbands, w, h, pre, npre, pre_xy, xj_check, min_contrast, dedupe_radius, fc, kept_out, kept_xy_out);
+  validate_frame<256>(sm, blockIdx.x, threadIdx.x, bin, grey, thr, nbands, w, h, pre, npre, pre_xy, pre_stride, max_kept, xj_check, min_contrast, dedupe_radius, fc, kept_out, kept_xy_out);
 }
 
 __global__ __launch_bounds__(64) void k_grid_index(int w, int h, const rcc_cand* __restrict__ kept, const double* __restrict__ kept_xy,
@@ -37,7 +37,8 @@ hipError_t rcc_launch_validate(rcc_handle* h, const uint8_t* d_grey, const uint8
   const int nbands = (c.width + RCC_BAND_W - 1) / RCC_BAND_W;
   hipLaunchKernelGGL(k_validate, dim3(nframes), dim3(256), 0, s, h->bin_from_thr ? nullptr : d_bin, d_grey,
                      h->bin_from_thr ? h->d_thr : nullptr, nbands, c.width, c.height,
-                     h->d_pre, h->d_npre, h->d_pre_xy, c.xj_check, c.thr_min_contrast, 2, h->d_fc, h->d_kept, h->d_kept_xy);
+                     h->d_pre, h->d_npre, h->d_pre_xy, h->kept_cap, c.max_kept < RCC_MAX_KEPT ? c.max_kept : RCC_MAX_KEPT, c.xj_check, c.thr_min_contrast, 2,
+                     h->d_fc, h->d_kept, h->d_kept_xy);
   return hipGetLastError();
 }
 

@@ -166,7 +166,9 @@ hipError_t rcc_launch_list(rcc_handle* h, const rcc_cand* d_cand, const int32_t*
 {
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
-  int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
+  // capacity of the list after suppression: tag scenes cfg.max_kept (<= 2048); board scenes the full 2048 -- cfg.max_kept (<= 256)
+  // bounds the validated list of a4.3 there (k_validate)
+  int max_kept = (c.target_kind == RCC_TARGET_FIDUCIAL && c.max_kept < h->kept_cap) ? c.max_kept : h->kept_cap;
   const bool buckets = c.height <= LIST_MAXH - 1;
   const size_t lds = 2 * (size_t)c.max_candidates * sizeof(rcc_cand) + 2 * (size_t)(buckets ? ((c.height + 2 + 7) & ~7) : 8) * sizeof(unsigned short) +
                      (256 + 257) * sizeof(int);

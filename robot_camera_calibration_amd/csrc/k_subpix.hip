@@ -39,31 +39,36 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   if ((int)blockIdx.x >= np) return;
   const int lane = threadIdx.x;
   const uint8_t* g = grey + (size_t)f * w * h;
-  if (!FID && gate_contrast >= 0) {
-    // Board scenes: is the candidate worth refining?  The 36 L-shaped corners on the outline of a 9 x 7-square board took 42 % of
-    // this stage's iterations only to be rejected by a4.3.  Lanes 0..15 read the radius-11 ring around the candidate's pixel (a
-    // Harris maximum sits up to ~3 px off its junction, 6.5 px under heavy blur: the ring still encloses it); fewer than four transitions against the
-    // ring's own mid level, or a ring that does not span min_contrast: not a junction -- the wave writes (-1, -1), which a4.3
-    // rejects, and retires before it has loaded its tables.  A ring that leaves the image passes.
-    const rcc_cand c0 = pre[(size_t)f * kstride + blockIdx.x];
+  // Board scenes: is candidate q worth refining?  The 36 L-shaped corners on the outline of a 9 x 7-square board took 42 % of this
+  // stage's iterations only to be rejected by a4.3, and a cluttered scene brings hundreds of such candidates.  Lanes 0..15 read the
+  // radius-11 ring around the candidate's pixel (a Harris maximum sits up to ~3 px off its junction, 6.5 px under heavy blur: the
+  // ring still encloses it); fewer than four transitions against the ring's own mid level, or a ring that does not span
+  // min_contrast: not a junction -- the wave writes (-1, -1), which a4.3 rejects.  A ring that leaves the image passes.
+  auto gated = [&](const int q) -> bool {
+    const rcc_cand c0 = pre[(size_t)f * kstride + q];
     const int xi = c0.x, yi = c0.y;
-    if (xi >= 11 && yi >= 11 && xi < w - 11 && yi < h - 11) {                         // wave-uniform
-      const int k = lane & 15;
-      const int v = (int)g[(size_t)(yi + c_ring11[k][1]) * w + (xi + c_ring11[k][0])];
-      int lo = v, hi = v;
+    if (!(xi >= 11 && yi >= 11 && xi < w - 11 && yi < h - 11)) return false;      // wave-uniform
+    const int k = lane & 15;
+    const int v = (int)g[(size_t)(yi + c_ring11[k][1]) * w + (xi + c_ring11[k][0])];
+    int lo = v, hi = v;
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
-      const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(v > ((lo + hi) >> 1)) & 0xFFFFu;
-      const unsigned rotl = ((bits << 1) | (bits >> 15)) & 0xFFFFu;
-      const int lo0 = __builtin_amdgcn_readfirstlane(lo), hi0 = __builtin_amdgcn_readfirstlane(hi);
-      if (hi0 - lo0 < gate_contrast || __popc(bits ^ rotl) < 4) {
-        if (lane == 0) {
-          pre_xy[((size_t)f * kstride + blockIdx.x) * 2] = -1.0;
-          pre_xy[((size_t)f * kstride + blockIdx.x) * 2 + 1] = -1.0;
-        }
-        return;
-      }
+    for (int off = 1; off < 16; off <<= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
+    const unsigned bits = (unsigned)__builtin_amdgcn_ballot_w64(v > ((lo + hi) >> 1)) & 0xFFFFu;
+    const unsigned rotl = ((bits << 1) | (bits >> 15)) & 0xFFFFu;
+    const int lo0 = __builtin_amdgcn_readfirstlane(lo), hi0 = __builtin_amdgcn_readfirstlane(hi);
+    if (hi0 - lo0 >= gate_contrast && __popc(bits ^ rotl) >= 4) return false;
+    if (lane == 0) {
+      pre_xy[((size_t)f * kstride + q) * 2] = -1.0;
+      pre_xy[((size_t)f * kstride + q) * 2 + 1] = -1.0;
     }
+    return true;
+  };
+  // a wave whose only candidate is gated retires before it has loaded its tables (the common case: a board frame's list is
+  // shorter than the grid is wide)
+  bool first_passed = false;
+  if (!FID && gate_contrast >= 0 && (int)blockIdx.x + qstep >= np) {
+    if (gated((int)blockIdx.x)) return;
+    first_passed = true;
   }
   const int win = sp.win;
   const int ww = 2 * win + 1, pw = 2 * win + 3;
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   constexpr bool fid = FID;
   const int per_pass = fid ? 4 : 1;
   for (int q0 = blockIdx.x; q0 < np; q0 += per_pass * qstep) {
+  if (!FID && gate_contrast >= 0 && !(first_passed && q0 == (int)blockIdx.x) && gated(q0)) continue;
   unsigned refine_m = 1u;                  // bit k: candidate q0 + k * qstep is refined
   int cgx = 0, cgy = 0;                    // fid: the candidate of this lane's group of 16
   if (fid) {
@@ -229,8 +235,10 @@ hipError_t rcc_launch_subpix(rcc_handle* h, const uint8_t* d_grey, int nframes, 
 {
   const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
-  int max_kept = c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap;
   const bool fid = c.target_kind == RCC_TARGET_FIDUCIAL;
+  // board scenes: a grid 256 wide (the bench's frames hold 85-130 candidates); a cluttered frame's longer list (up to 2048) is
+  // walked by the same waves
+  int max_kept = fid ? (c.max_kept < h->kept_cap ? c.max_kept : h->kept_cap) : RCC_MAX_KEPT;
   // tag scenes: the grid is narrower than the list (measured on 1024 x 1080p with ~750 candidates per frame: width 2048 /
   // 512 / 256 / 128 / 64 / 32 / 16: 0.63 / 0.55 / 0.49 / 0.46 / 0.44 / 0.48 / 0.52 ms) -- at least 64 wide, and wide
   // enough that a small batch still puts four waves on every slot of the device

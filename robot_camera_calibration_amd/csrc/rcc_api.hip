@@ -162,7 +162,8 @@ int rcc_create(const rcc_config* cfg, rcc_handle** out)
   h->ingest_variant = -1;
   h->dense_skip = 1;
   h->pnp_variant = -1;
-  h->kept_cap = (cfg->target_kind == RCC_TARGET_FIDUCIAL) ? RCC_MAX_KEPT_FIDUCIAL : RCC_MAX_KEPT;
+  h->kept_cap = RCC_MAX_KEPT_FIDUCIAL;      // capacity (and stride) of the per-frame lists after suppression, whatever the target: the
+                                            // board path's cfg.max_kept (<= 256) bounds the VALIDATED list only (round 4: cluttered scenes)
   h->pnp_solver = 1;
   h->pnp_use_mfma = cfg->pnp_use_mfma ? 1 : 0;
   h->ingest_table = 1;

@@ -165,6 +165,39 @@ def test_pipeline_rgb8(torch_cuda, oracle, w, h, undistort):
     assert (greys[abi.RCC_PIX_RGB8] == greys[abi.RCC_PIX_BGR8]).all()
 
 
+@pytest.mark.parametrize("count,lo,hi", [(100, 8, 60), (400, 8, 60), (900, 8, 40), (4000, 6, 14)], ids=["100", "400", "900", "4000_small"])
+def test_pipeline_cluttered_board_scenes(torch_cuda, oracle, count, lo, hi):
+    """round 4: the board path takes up to 2048 candidates after suppression (cfg.max_kept bounds the validated list only), so a
+    scene full of other objects no longer loses the board at ~100 of them.  Rectangles all over 1280x720 frames, two of them with
+    the clutter ON the board as well: every stage of every frame against the oracle -- found, rejected for overflow or not found,
+    the two sides agree; with the board left alone it is found."""
+    from tests.util import clutter_bgr
+    torch = torch_cuda
+    n, W, H = 6, 1280, 720
+    def mod(c):
+        c.max_candidates = 4096
+    cfg = _make(mod, w=W, h=H, B=n)
+    det = api.Detector(cfg)
+    frames, poses = _render(torch, det, cfg, n, seed=321, z_range=(1.5, 2.5))
+    det.close()
+    host = frames.cpu().numpy().reshape(n, H, W, 3)
+    K = np.array(list(cfg.K)); objb = synth.board_object_points(8, 6, 0.108)
+    for f in range(n):
+        gt = synth.project_points(objb, poses[f][:3], poses[f][3:], K)
+        ko = (gt[:, 0].min() - 90, gt[:, 1].min() - 90, gt[:, 0].max() + 90, gt[:, 1].max() + 90) if f < 4 else None
+        host[f] = clutter_bgr(host[f], 10 * count + f, count, ko, lo, hi)
+    frames = torch.from_numpy(host.reshape(n, -1)).cuda()
+    mx, found = _check_batch(torch, oracle, cfg, frames, n, expect_found=False)
+    det = api.Detector(cfg)
+    dets, fcs = det.detect(frames, n)
+    lst = det.fetch_lists(n)
+    det.close()
+    print("clutter %d: npre %s, found %d of %d, status %s" % (count, lst["npre"].tolist(), found, n, [int(fc.status) for fc in fcs]))
+    if count <= 400:         # (beyond: the validated clutter outnumbers what the lattice stage's eight seeds find the board among)
+        assert lst["npre"][:4].min() > (256 if count >= 400 else 100)
+        assert all(int(fcs[f].status) == 0 and int(fcs[f].ncorners) == 48 for f in range(4))
+
+
 def test_pipeline_mono_raw_distortion_in_pnp(torch_cuda, oracle):
     """undistort = 0: detector on the raw image, PnP with D -- the reference's own arrangement
     (camera_pose.cpp:163 passes kdistCoeffs)"""

@@ -295,6 +295,44 @@ def test_junction_gate_holds_back_the_outline_not_the_corners(oracle):
         ctx.close()
 
 
+def test_board_in_a_cluttered_scene(oracle):
+    """round 4: the list after suppression holds 2048 entries for the board too, and cfg.max_kept (<= 256) bounds only what passes
+    a4.3's ring tests.  Rounds 1-3 rejected a frame beyond 256 suppressed candidates -- about a hundred objects in view.  Rectangles
+    all over the scene (not on the board): the board is found with several hundred candidates in the list, the clutter is held back
+    by a5's gate and a4.3, and the corners are those of the empty scene."""
+    from tests.util import clutter_bgr
+    W, H = 1280, 720
+    cfg = oracle.default_config()
+    abi.set_geometry(cfg, W, H, abi.RCC_PIX_BGR8)
+    sp = abi.default_synth_params(seed=5)
+    pose = synth.sample_poses(1, cfg, seed=5, z_range=(1.5, 2.5))[0]
+    img = oracle.synth_render(cfg, sp, pose, 0)
+    K = np.array(list(cfg.K))
+    gt = synth.project_points(synth.board_object_points(8, 6, 0.108), pose[:3], pose[3:], K)
+    ko = (gt[:, 0].min() - 100, gt[:, 1].min() - 100, gt[:, 0].max() + 100, gt[:, 1].max() + 100)
+    ctx = oracle.Context(cfg)
+    n0, det0, fc0, st0 = ctx.detect(img, 0, stages=True)
+    assert n0 == 1 and st0["npre"] < 100
+    for count in (100, 200, 300):
+        c = clutter_bgr(img, 1000 + count, count, ko)
+        n, det, fc, st = ctx.detect(c, 0, stages=True)
+        print("clutter %d: %d candidates after suppression, %d validated" % (count, st["npre"], st["nkept"]))
+        assert st["npre"] > (256 if count > 100 else 150) and fc.status == 0 and n == 1 and fc.ncorners == 48, (count, st["npre"], fc.status)
+        assert st["nkept"] <= 256
+        assert np.abs(np.array(fc.xy[:48]) - np.array(fc0.xy[:48])).max() == 0.0            # the board's corners are untouched by the clutter
+        held = (st["pre_xy"] == -1.0).all(1)
+        assert held.sum() > 0.5 * st["npre"]                                              # most of the clutter never gets refined
+    # junction-like clutter beyond the validated list's capacity: overlapping small rectangles everywhere -> the frame is refused whole
+    dense = clutter_bgr(img, 77, 4000, ko, lo=6, hi=14)
+    cfg2 = oracle.default_config()
+    abi.set_geometry(cfg2, W, H, abi.RCC_PIX_BGR8)
+    cfg2.max_candidates = 4096
+    ctx2 = oracle.Context(cfg2)
+    n, det, fc, st = ctx2.detect(dense, 0, stages=True)
+    assert n == 0 and fc.status in (abi.RCC_FRAME_KEPT_OVERFLOW, abi.RCC_FRAME_CAND_OVERFLOW, abi.RCC_FRAME_NOT_FOUND)
+    ctx.close(); ctx2.close()
+
+
 # ---------------------------------------------------------------- a5
 @pytest.mark.parametrize("x0,y0,ang", [(31.3, 30.6, 0.3), (32.0, 32.0, 0.0), (30.75, 33.4, 0.9), (33.49, 29.51, -0.5)])
 def test_subpix_converges_to_saddle(oracle, x0, y0, ang):

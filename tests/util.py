@@ -25,3 +25,21 @@ def sorted_cands(c):
     c = np.asarray(c)
     order = np.lexsort((c["x"], c["y"]))
     return c[order]
+
+
+def clutter_bgr(img, seed, count, keep_out=None, lo=8, hi=60):
+    """paste `count` random rectangles of random colour over a BGR frame (h, w, 3), leaving the box keep_out = (x0, y0, x1, y1)
+    alone: corners, edges and -- where rectangles overlap -- junction-like points all over the scene"""
+    rng = np.random.default_rng(seed)
+    out = img.copy()
+    h, w = out.shape[:2]
+    n = tries = 0
+    while n < count and tries < 50 * count:
+        tries += 1
+        rw, rh = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
+        x, y = int(rng.integers(0, w - rw)), int(rng.integers(0, h - rh))
+        if keep_out is not None and x < keep_out[2] and x + rw > keep_out[0] and y < keep_out[3] and y + rh > keep_out[1]:
+            continue
+        out[y:y + rh, x:x + rw] = rng.integers(0, 256, 3)
+        n += 1
+    return out
