@@ -2,7 +2,8 @@
 """Container-only generator of tests/golden/image_xcheck.npz: an INDEPENDENT derivation of the image stages a1-a5
  in numpy / scipy.ndimage -- whole-array filters, reshapes and broadcasting instead of the oracle's
 pixel loops, np.sum instead of its 64-bin tree, np.arctan instead of its own arctangent -- on three small synthetic
-frames rendered here (not by the oracle's or the library's synthetic camera).
+frames rendered here (not by the oracle's or the library's synthetic camera); since round 4 also a5's gate and a4.3 (ring tests on the
+threshold image and on the grey image, de-duplication) as whole-array gathers.
 
 What it pins: the oracle (tests/test_golden.py, CPU) and the HIP path (tests/test_gpu_parity.py, GPU) must both
 reproduce these arrays: grey, Q5 maps and remapped images, threshold images, candidate lists, suppressed lists bit for
@@ -200,6 +201,55 @@ def corner_subpix(grey, pts, win, max_iter, eps):
     return out
 
 
+# ---- a5's gate and a4.3 (round 4): ring samples as whole-array gathers, transitions by np.roll, de-duplication pairwise -------------
+def ring_offsets(radius):
+    """the 16 ring positions: the pixel nearest to the circle point every 22.5 degrees, counter-clockwise from +x"""
+    ang = 2.0 * np.pi * np.arange(16) / 16.0
+    return np.stack([np.rint(radius * np.cos(ang)), np.rint(radius * np.sin(ang))], 1).astype(np.int64)
+
+
+def _transitions(above):
+    return (above != np.roll(above, -1, axis=1)).sum(1)
+
+
+def gate_np(grey, pts, min_contrast, radius=11):
+    """a5's gate at the UNREFINED pixel: the grey ring of that radius, cut at its own mid level, changes side at least four times and
+    spans min_contrast; a ring that leaves the image passes"""
+    h, w = grey.shape
+    x, y = pts[:, 0].astype(np.int64), pts[:, 1].astype(np.int64)
+    room = (x >= radius) & (y >= radius) & (x < w - radius) & (y < h - radius)
+    ro = ring_offsets(radius)
+    g = grey[np.where(room, y, radius)[:, None] + ro[None, :, 1], np.where(room, x, radius)[:, None] + ro[None, :, 0]].astype(np.int64)
+    lo, hi = g.min(1), g.max(1)
+    ok = (hi - lo >= min_contrast) & (_transitions(g > ((lo + hi) >> 1)[:, None]) >= 4)
+    return np.where(room, ok, True)
+
+
+def validate_np(pre, xy, binimg, grey, min_contrast, dedupe=2):
+    """a4.3: the rounded refined position has a radius-5 ring inside the image on which the threshold image shows no flat sample and
+    exactly four changes AND the grey ring, cut at its own mid level, spans min_contrast with exactly four changes; of two such
+    entries within +-dedupe pixels the one with the larger score stays (equal: the earlier in the list).  Returns (x, y, score) rows
+    and the refined positions, in list order."""
+    h, w = grey.shape
+    xi = np.floor(xy[:, 0] + 0.5).astype(np.int64)
+    yi = np.floor(xy[:, 1] + 0.5).astype(np.int64)
+    room = (xi >= 5) & (yi >= 5) & (xi < w - 5) & (yi < h - 5)
+    ro = ring_offsets(5)
+    yy = np.where(room, yi, 5)[:, None] + ro[None, :, 1]
+    xx = np.where(room, xi, 5)[:, None] + ro[None, :, 0]
+    b = binimg[yy, xx].astype(np.int64)
+    g = grey[yy, xx].astype(np.int64)
+    lo, hi = g.min(1), g.max(1)
+    ok = room & (b != 127).all(1) & (_transitions(b) == 4) & (hi - lo >= min_contrast) & (_transitions(g > ((lo + hi) >> 1)[:, None]) == 4)
+    idx = np.nonzero(ok)[0]
+    px, py, sc = xi[idx], yi[idx], pre[idx, 2].astype(np.int64)
+    near = (np.abs(px[:, None] - px[None, :]) <= dedupe) & (np.abs(py[:, None] - py[None, :]) <= dedupe)
+    order = np.arange(len(idx))
+    beats = near & ((sc[None, :] > sc[:, None]) | ((sc[None, :] == sc[:, None]) & (order[None, :] < order[:, None])))      # [a, b]: b beats a
+    keep = ~beats.any(1)
+    return np.stack([px[keep], py[keep], sc[keep]], 1), xy[idx][keep]
+
+
 # ---- a4.3 + a6: where the 8 x 6 inner corners of each view lie, and in which order they must be reported ------------------
 def ideal_corners(view, cols=8, rows=6):
     """image positions of the inner corners from the view's own projective map (the inverse of render's), ordered by
@@ -368,6 +418,21 @@ def main():
     out["pre"] = np.concatenate(pres); out["pre_n"] = np.array([len(p) for p in pres])
     out["pre_xy"] = np.concatenate(xys)
     out["ideal_xy"] = np.stack([ideal_corners(v) for v in views])
+    # a5's gate and a4.3 at min_contrast 32 (round 4): gated entries are not refined and reach a4.3 as (-1, -1)
+    gates, kepts, kxys = [], [], []
+    for f, g in enumerate(grey):
+        gt = gate_np(g, pres[f], 32)
+        gxy = np.where(gt[:, None], xys[f], -1.0)
+        k, kxy = validate_np(pres[f], gxy, out["bin32"][f], g, 32)
+        gates.append(gt); kepts.append(k); kxys.append(kxy)
+    # a4.3 alone on EVERY refined entry (no gate in front), at both contrast settings: more entries reach the ring tests
+    for mc, key in ((32, "bin32"), (5, "bin5")):
+        ka = [validate_np(pres[f], xys[f], out[key][f], g, mc)[0] for f, g in enumerate(grey)]
+        out["keptall%d" % mc] = np.concatenate(ka); out["keptall%d_n" % mc] = np.array([len(k) for k in ka])
+        print("a4.3 on every refined entry, min_contrast %d: validated" % mc, out["keptall%d_n" % mc])
+    out["gate32"] = np.concatenate(gates)
+    out["kept32"] = np.concatenate(kepts); out["kept32_n"] = np.array([len(k) for k in kepts]); out["kept32_xy"] = np.concatenate(kxys)
+    print("gate (numpy): held back", [int((~g_).sum()) for g_ in gates], "of", [len(g_) for g_ in gates], "; validated", out["kept32_n"])
     K = np.array([0.9 * W, 0.0, (W - 1) * 0.5, 0.0, 0.9 * W, (H - 1) * 0.5, 0.0, 0.0, 1.0])
     cams = [(1, np.array([-0.28, 0.07, 2e-4, -1e-4, 0.0, 0, 0, 0])), (1, np.array([-0.45, 0.25, 3e-3, -2e-3, -0.05, 0, 0, 0])),
             (2, np.array([-0.2, 0.05, -0.01, 0.002, 0, 0, 0, 0]))]
