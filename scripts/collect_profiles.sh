@@ -17,7 +17,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/dense_sq1 -o p --output-format csv -- python3 $R/scripts/prof_dense.py 512 > $O/dense_sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VMEM_TA_ADDR_FIFO_FULL SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY -d $O/dense_sq2 -o p --output-format csv -- python3 $R/scripts/prof_dense.py 512 > $O/dense_sq2.log 2>&1
+# the ingest pass's instruction mix (round 4: it runs with its vector pipes ~70 % busy AND at ~87 % of the achievable HBM rate)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/ingest_sq1 -o p --output-format csv -- python3 $R/scripts/prof_ingest.py 256 > $O/ingest_sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VMEM_TA_ADDR_FIFO_FULL SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY -d $O/ingest_sq2 -o p --output-format csv -- python3 $R/scripts/prof_ingest.py 256 > $O/ingest_sq2.log 2>&1
 cd $R
+python3 scripts/pmc_table.py $O/ingest_sq1 k_ingest > $O/ingest_sq.txt
+python3 scripts/pmc_table.py $O/ingest_sq2 k_ingest >> $O/ingest_sq.txt
 python3 scripts/summarize_pmc.py $O/dense_FETCH_SIZE/p_counter_collection.csv $O/dense_WRITE_SIZE/p_counter_collection.csv 512 $TAG "k_dense_band<0" 4147200 k_calib_copy_x4 dense > $O/dense_traffic.txt
 python3 scripts/summarize_pmc.py $O/dense_FETCH_SIZE/p_counter_collection.csv $O/dense_WRITE_SIZE/p_counter_collection.csv 512 $TAG k_dense_wave 2203200 k_calib_copy_x4 dense_step > $O/dense_step_traffic.txt
 python3 scripts/summarize_pmc.py $O/ingest_FETCH_SIZE/p_counter_collection.csv $O/ingest_WRITE_SIZE/p_counter_collection.csv 256 $TAG k_ingest_staged 8294400 > $O/ingest_traffic.txt
