@@ -221,7 +221,7 @@ int orc_grid_index(const orc_cand* pts, int n, int cols, int rows, int32_t* orde
   for (int i = 0; i < n; ++i) { p[i].x = pts[i].x; p[i].y = pts[i].y; sx += p[i].x; sy += p[i].y; }
 
   /* seeds: the 8 points closest to the centroid, closest first (compare |n*p - sum|^2) */
-  int seeds[8];
+  int seeds[16];
   int nseeds = 0;
   {
     uint8_t taken[GMAXPTS];
@@ -236,6 +236,26 @@ int orc_grid_index(const orc_cand* pts, int n, int cols, int rows, int32_t* orde
         if (best < 0 || d < bd) { best = i; bd = d; }
       }
       taken[best] = 1;
+      seeds[nseeds++] = best;
+    }
+  }
+
+  /* [B] round 4: should none of them grow the board -- clutter all over the scene pulls the centroid off it -- up to 8 more seeds
+   * follow: the points with the largest score (Harris response) that have not been tried, largest first, ties to the smaller
+   * index.  A board's corners are the strongest junctions of most scenes.  A frame whose board grows from a centroid seed is
+   * untouched by this. */
+  {
+    uint8_t tried[GMAXPTS];
+    memset(tried, 0, sizeof(tried));
+    for (int q = 0; q < nseeds; ++q) tried[seeds[q]] = 1;
+    const int ncentroid = nseeds;
+    for (int s2 = 0; s2 < 8 && ncentroid + s2 < n; ++s2) {
+      int best = -1;
+      for (int i = 0; i < n; ++i) {
+        if (tried[i]) continue;
+        if (best < 0 || pts[i].score > pts[best].score) best = i;
+      }
+      tried[best] = 1;
       seeds[nseeds++] = best;
     }
   }

@@ -302,7 +302,8 @@ struct grid_smem {
 };
 // the lattice of a board frame from its validated points (list order in sm.px / sm.py): J = 1 for at most 64 points, else 4
 template <int J>
-__device__ __forceinline__ bool lattice_board(grid_smem& sm, const int f, const int lane, const int nk, const int cols, const int rows, const int need, const bool small)
+__device__ __forceinline__ bool lattice_board(grid_smem& sm, const int f, const int lane, const int nk, const int cols, const int rows, const int need, const bool small,
+                                              const rcc_cand* __restrict__ kept_f /* the frame's validated list (scores of the second seed group) */)
 {
   bool found_board = false;
   int pxr[J], pyr[J];
@@ -317,7 +318,7 @@ __device__ __forceinline__ bool lattice_board(grid_smem& sm, const int f, const 
   for (int j = 0; j < J; ++j) if (lane + 64 * j < nk) { sx += pxr[j]; sy += pyr[j]; }
   sx = wave_sum_i64(sx);
   sy = wave_sum_i64(sy);
-  // seeds: the 8 points nearest the centroid, nearest first; seed s is kept in lane s of seedreg
+  // seeds: the 8 points nearest the centroid, nearest first; seed s is kept in lane s of seedreg (a second group, by score, below)
   unsigned takenm = 0;
   int seedreg = 0;
   const int nseeds = nk < 8 ? nk : 8;
@@ -341,7 +342,30 @@ __device__ __forceinline__ bool lattice_board(grid_smem& sm, const int f, const 
   // packed cell offsets of the 3 x 3 neighbourhood a lane < 9 reads: cell (i + lane / 3 - 1, j + lane % 3 - 1)
   const int nb_off = (lane < 9) ? ((lane / 3 - 1) * GW + (lane % 3 - 1)) : 0;
 
-  for (int si = 0; si < nseeds && !found_board; ++si) {
+  // round 4: should no centroid seed grow the board (clutter all over the scene pulls the centroid off it), up to 8 more follow: the
+  // points with the largest score that have not been tried, largest first, ties to the smaller index -- computed only when needed
+  const int nseeds2 = (nk - nseeds) < 8 ? (nk - nseeds) : 8;
+  for (int si = 0; si < nseeds + nseeds2 && !found_board; ++si) {
+    if (si == nseeds) {                 // wave-uniform
+      int scr[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) { const int k = lane + 64 * j; scr[j] = (k < nk) ? kept_f[k].score : 0; }
+      for (int s2 = 0; s2 < nseeds2; ++s2) {
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int i = lane + 64 * j;
+          if (i < nk && !((takenm >> j) & 1u)) {
+            const unsigned long long key = ((unsigned long long)(~((unsigned)scr[j] ^ 0x80000000u)) << 8) | (unsigned long long)i;     // larger (signed) score = smaller key
+            best = key < best ? key : best;
+          }
+        }
+        best = wave_min_u64(best);
+        const int bi = uni((int)(best & 255ull));
+        if (lane == (bi & 63)) takenm |= 1u << (bi >> 6);
+        if (lane == nseeds + s2) seedreg = bi;
+      }
+    }
     const int s = uni(__builtin_amdgcn_readlane(seedreg, si));
     __syncthreads();
     for (int i = lane; i < GW * GW; i += 64) sm.labp[i] = -1;
@@ -524,7 +548,8 @@ __device__ __forceinline__ bool index_frame(grid_smem& sm, const int f, const in
   bool found_board = false;
   if (target_kind == RCC_TARGET_CHECKERBOARD && nk >= need && nk <= RCC_MAX_KEPT && cols >= 2 && rows >= 2 &&
       cols <= GBOARD && rows <= GBOARD && need <= RCC_MAX_BOARD_CORNERS) {
-    found_board = (nk <= 64) ? lattice_board<1>(sm, f, lane, nk, cols, rows, need, small) : lattice_board<4>(sm, f, lane, nk, cols, rows, need, small);
+    const rcc_cand* kf = kept + (size_t)f * RCC_MAX_KEPT;
+    found_board = (nk <= 64) ? lattice_board<1>(sm, f, lane, nk, cols, rows, need, small, kf) : lattice_board<4>(sm, f, lane, nk, cols, rows, need, small, kf);
   }
   if (found_board) {
     for (int k = lane; k < need; k += 64) {

@@ -193,7 +193,7 @@ def test_pipeline_cluttered_board_scenes(torch_cuda, oracle, count, lo, hi):
     lst = det.fetch_lists(n)
     det.close()
     print("clutter %d: npre %s, found %d of %d, status %s" % (count, lst["npre"].tolist(), found, n, [int(fc.status) for fc in fcs]))
-    if count <= 400:         # (beyond: the validated clutter outnumbers what the lattice stage's eight seeds find the board among)
+    if count <= 900:         # (900: found through the second seed group -- by score -- where the centroid seeds lie in the clutter)
         assert lst["npre"][:4].min() > (256 if count >= 400 else 100)
         assert all(int(fcs[f].status) == 0 and int(fcs[f].ncorners) == 48 for f in range(4))
 

@@ -313,7 +313,7 @@ def test_board_in_a_cluttered_scene(oracle):
     ctx = oracle.Context(cfg)
     n0, det0, fc0, st0 = ctx.detect(img, 0, stages=True)
     assert n0 == 1 and st0["npre"] < 100
-    for count in (100, 200, 300):
+    for count in (100, 200, 300, 600, 1000):       # (600, 1000: found through the second seed group, by score -- the centroid seeds lie in the clutter)
         c = clutter_bgr(img, 1000 + count, count, ko)
         n, det, fc, st = ctx.detect(c, 0, stages=True)
         print("clutter %d: %d candidates after suppression, %d validated" % (count, st["npre"], st["nkept"]))
@@ -395,6 +395,41 @@ def test_grid_index_rejects_incomplete(oracle):
         p = np.delete(truth, drop, axis=0)
         cand = np.zeros(len(p), oracle.CAND_DT); cand["x"] = p[:, 0]; cand["y"] = p[:, 1]
         assert not oracle.grid_index(cand, 8, 6)[0]
+
+
+def test_grid_index_second_seed_group_by_score(oracle):
+    """round 4: where no centroid seed grows the board, the strongest points are tried.  A lattice in one corner of a field of weaker
+    points: the centroid and its eight nearest points lie in the clutter, the lattice's points carry the largest scores -> found,
+    and found identically when the clutter is absent.  With the scores the other way round (the clutter stronger) nothing is found:
+    the rule is the definition's, not a search over every point."""
+    rng = np.random.default_rng(4)
+    H = np.eye(3); H[:2, :2] *= 22; H[:2, 2] = [60, 50]
+    truth = np.rint(_lattice(8, 6, H)).astype(int)                                   # x 60..214, y 50..160
+    far = rng.uniform([300, 200], [1200, 700], (150, 2))                            # well away from the lattice
+    far = np.rint(far).astype(int)
+    far = far[np.unique(far[:, 0] * 4096 + far[:, 1], return_index=True)[1]]
+    keep = [0]
+    for i in range(1, len(far)):                                                    # no two clutter points closer than 12 px (the list is suppressed)
+        if np.abs(far[keep] - far[i]).max(1).min() > 12:
+            keep.append(i)
+    far = far[keep]
+    assert len(far) > 80
+
+    def run(lattice_score, clutter_score):
+        allp = np.concatenate([truth, far])
+        sc = np.concatenate([np.full(len(truth), lattice_score), np.full(len(far), clutter_score)])
+        order = np.lexsort((allp[:, 0], allp[:, 1]))
+        cand = np.zeros(len(allp), oracle.CAND_DT)
+        cand["x"] = allp[order, 0]; cand["y"] = allp[order, 1]; cand["score"] = sc[order]
+        ok, idx = oracle.grid_index(cand, 8, 6)
+        return ok, (np.stack([cand["x"][idx], cand["y"][idx]], 1) if ok else None)
+    ok, got = run(900000, 30000)
+    assert ok
+    alone = np.zeros(48, oracle.CAND_DT); alone["x"] = truth[:, 0]; alone["y"] = truth[:, 1]; alone["score"] = 900000
+    ok0, idx0 = oracle.grid_index(alone, 8, 6)
+    assert ok0 and (got == np.stack([alone["x"][idx0], alone["y"][idx0]], 1)).all()
+    assert not run(30000, 900000)[0]
+    assert run(50000, 50000)[0]              # equal scores: ties go to the smaller index, and the list is ordered by (y, x) -- the lattice's first row here
 
 
 def test_board_object_points_follow_reference_convention():
