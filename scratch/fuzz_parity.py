@@ -87,6 +87,24 @@ while time.time() - t0 < budget:
             det.synth_render(sp, poses, frames)
             torch.cuda.synchronize()
             det.close()
+            if pix == abi.RCC_PIX_BGR8 and rng.random() < 0.3:
+                # other objects in view (round 4): rectangles of random colour all over the frames, sometimes over the board too -- the
+                # long suppressed lists, the validated list's capacity, the second seed group and the overflow statuses
+                from tests.util import clutter_bgr
+                count, lo_, hi_ = [(50, 8, 60), (200, 8, 60), (600, 8, 50), (1500, 8, 40), (4000, 6, 14)][int(rng.integers(5))]
+                cfg.max_candidates = int(rng.choice([2048, 4096]))
+                host = frames.cpu().numpy().reshape(n, h, w, 3)
+                Kc = np.array(list(cfg.K)); objb = synth.board_object_points(cfg.board_cols, cfg.board_rows, cfg.board_square)
+                for f in range(n):
+                    ko = None
+                    if rng.random() < 0.7 and not cfg.undistort:
+                        gt = synth.project_points(objb, poses[f][:3], poses[f][3:], Kc)
+                        ko = (gt[:, 0].min() - 60, gt[:, 1].min() - 60, gt[:, 0].max() + 60, gt[:, 1].max() + 60)
+                    elif rng.random() < 0.7:
+                        ko = (w * 0.2, h * 0.2, w * 0.8, h * 0.8)
+                    host[f] = clutter_bgr(host[f], seed + f, count, ko, lo_, hi_)
+                frames = torch.from_numpy(np.ascontiguousarray(host).reshape(n, -1)).cuda()
+                desc.update(clutter=count, maxc=cfg.max_candidates)
             mx, found = T._check_batch(torch, oracle, cfg, frames, n, expect_found=False)
             found_total += found
         frames_total += n
