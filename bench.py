@@ -635,6 +635,12 @@ def main():
     gather = rdist.PoseGather(B, dev, world, dist, rank, targets_per_frame=tpf, inline=not a.gather_side_stream)
     if dist is not None:
         gather.attach(det, frame_offset=first)      # the detector packs the records on the device, every batch
+        # torch loads a kernel's code object the first time it is launched: the compare + sum behind gather.count() took ~65 ms when
+        # they first ran at the end of the warm-up -- the device idled that long in front of the timed region, its clock fell, and the
+        # region's first four steps ran at 3.2 / 3.2 / 3.0 / 2.9 ms instead of 2.75 (steps_trace.device_idle_before_ms_all[0] of the
+        # world-of-one runs of rounds 3-4).  Run them once here, long before the warm-up.
+        gather.count()
+        torch.cuda.synchronize()
 
     def timed_region(sync_form, want_corners=False):
         """W warm-up steps IN THE FORM THAT IS TIMED (so that the code paths, pinned slots and event rings of that form have all
