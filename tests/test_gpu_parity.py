@@ -198,6 +198,26 @@ def test_pipeline_cluttered_board_scenes(torch_cuda, oracle, count, lo, hi):
         assert all(int(fcs[f].status) == 0 and int(fcs[f].ncorners) == 48 for f in range(4))
 
 
+def test_pipeline_board_found_through_second_seed_group(torch_cuda, oracle):
+    """round 4, a6 on the device: the scene of tests/test_oracle_kat.py::test_board_found_through_the_second_seed_group (no centroid seed
+    lies on the board) next to its clutter-free twin in one batch: every stage against the oracle, both boards found, same corners."""
+    from tests.util import off_centre_board_among_clutter
+    torch = torch_cuda
+    def mod(c):
+        c.max_candidates = 4096
+    cfg = _make(mod, w=1280, h=720, B=2)
+    img, plain, gt = off_centre_board_among_clutter(oracle, cfg)
+    frames = torch.from_numpy(np.ascontiguousarray(np.stack([img, plain])).reshape(2, -1)).cuda()
+    mx, found = _check_batch(torch, oracle, cfg, frames, 2, expect_found=True)
+    det = api.Detector(cfg)
+    dets, fcs = det.detect(frames, 2)
+    det.close()
+    assert found == 2 and len(dets) == 2 and int(fcs[0].ncorners) == 48 and int(fcs[0].nkept) > 100 and int(fcs[1].nkept) < 64
+    assert np.abs(np.asarray(fcs[0].xy[:48]) - np.asarray(fcs[1].xy[:48])).max() == 0.0
+    got = np.asarray(fcs[0].xy[:48])
+    assert np.abs(got[:, None, :] - gt[None, :, :]).max(2).min(1).max() < 0.3          # every corner within 0.3 px of a projected one
+
+
 def test_pipeline_mono_raw_distortion_in_pnp(torch_cuda, oracle):
     """undistort = 0: detector on the raw image, PnP with D -- the reference's own arrangement
     (camera_pose.cpp:163 passes kdistCoeffs)"""

@@ -333,6 +333,28 @@ def test_board_in_a_cluttered_scene(oracle):
     ctx.close(); ctx2.close()
 
 
+def test_board_found_through_the_second_seed_group(oracle):
+    """round 4, a6: a board off to one side among 900 rectangles.  The eight validated points nearest the centroid are all clutter (checked
+    here from the validated list), so no centroid seed can grow the board; the second group -- the strongest points -- does, and the
+    corners are those of the scene without the clutter."""
+    from tests.util import off_centre_board_among_clutter
+    cfg = oracle.default_config()
+    abi.set_geometry(cfg, 1280, 720, abi.RCC_PIX_BGR8)
+    cfg.max_candidates = 4096
+    img, plain, gt = off_centre_board_among_clutter(oracle, cfg)
+    ctx = oracle.Context(cfg)
+    n0, det0, fc0 = ctx.detect(plain, 1)
+    n, det, fc, st = ctx.detect(img, 1, stages=True)
+    kept = st["kept"][:st["nkept"]]
+    p = np.stack([kept["x"], kept["y"]], 1).astype(float)
+    d = ((p - p.mean(0)) ** 2).sum(1)
+    near = np.argsort(d, kind="stable")[:8]
+    assert all(np.abs(gt - p[i]).max(1).min() > 20 for i in near)                  # the centroid seeds: clutter, every one
+    assert n0 == 1 and n == 1 and fc.status == 0 and fc.ncorners == 48
+    assert np.abs(np.array(fc.xy[:48]) - np.array(fc0.xy[:48])).max() == 0.0
+    ctx.close()
+
+
 # ---------------------------------------------------------------- a5
 @pytest.mark.parametrize("x0,y0,ang", [(31.3, 30.6, 0.3), (32.0, 32.0, 0.0), (30.75, 33.4, 0.9), (33.49, 29.51, -0.5)])
 def test_subpix_converges_to_saddle(oracle, x0, y0, ang):

@@ -43,3 +43,18 @@ def clutter_bgr(img, seed, count, keep_out=None, lo=8, hi=60):
         out[y:y + rh, x:x + rw] = rng.integers(0, 256, 3)
         n += 1
     return out
+
+
+def off_centre_board_among_clutter(oracle, cfg):
+    """(frame h x w x 3, plain frame, ground-truth corners): a board in the lower right of a 1280x720 frame among 900 rectangles that
+    keep 70 px from it -- the eight validated points nearest the centroid of all validated points are clutter, so the lattice stage
+    finds the board only through its second seed group (the strongest points)"""
+    import numpy as np
+    from robot_camera_calibration_amd import abi, synth
+    w, h = cfg.width, cfg.height
+    pose = np.array([-0.2, 0.15, -0.3, 0.8, 0.38, 2.7])
+    sp = abi.default_synth_params(seed=77)
+    plain = np.asarray(oracle.synth_render(cfg, sp, pose, 1)).reshape(h, w, 3)
+    gt = synth.project_points(synth.board_object_points(8, 6, 0.108), pose[:3], pose[3:], np.array(list(cfg.K)))
+    ko = (gt[:, 0].min() - 70, gt[:, 1].min() - 70, gt[:, 0].max() + 70, gt[:, 1].max() + 70)
+    return clutter_bgr(plain, 4910, 900, ko, 8, 50), plain, gt
