@@ -191,6 +191,7 @@ int orc_validate_refined(const orc_cand* pre, int n, const double* xy, const uin
  * ---------------------------------------------------------------------------------------------- */
 #define GM 24                    /* labels span [-GM, GM] */
 #define GBOARD 16                /* max inner corners per side */
+#define GEXTRA 8    /* labels beyond cols x rows that the window rule of round 4 takes */
 #define GW (2 * GM + 1)
 #define GMAXPTS 256
 
@@ -339,36 +340,72 @@ int orc_grid_index(const orc_cand* pts, int n, int cols, int rows, int32_t* orde
         ++L;
       }
     }
-    if (L != need) continue;
-    /* The second seed axis may be a lattice diagonal (v + k*u) in a foreshortened view: the
-     * labelled set is then a sheared rectangle.  Undo the shear: first k in 0,1,-1,2,-2,3,-3 for
-     * which (i + k*j, j) fills a cols x rows (or rows x cols) box. */
+    if (L < need || L > need + GEXTRA) continue;
     int li[GMAXPTS], lj[GMAXPTS], lk[GMAXPTS], nl = 0;
     for (int i = -GM; i <= GM; ++i)
       for (int j = -GM; j <= GM; ++j)
         if (LAB(i, j) >= 0) { li[nl] = i; lj[nl] = j; lk[nl] = LAB(i, j); ++nl; }
     static const int SHEAR[7] = { 0, 1, -1, 2, -2, 3, -3 };
     int found = 0, transpose = 0, imin = 0, jmin = 0, shear = 0;
-    for (int si2 = 0; si2 < 7 && !found; ++si2) {
-      int k = SHEAR[si2];
-      int i0 = 1 << 20, i1 = -(1 << 20), j0 = 1 << 20, j1 = -(1 << 20);
-      for (int q = 0; q < nl; ++q) {
-        int ii = li[q] + k * lj[q], jj = lj[q];
-        if (ii < i0) i0 = ii;
-        if (ii > i1) i1 = ii;
-        if (jj < j0) j0 = jj;
-        if (jj > j1) j1 = jj;
+    if (L == need) {
+      /* The second seed axis may be a lattice diagonal (v + k*u) in a foreshortened view: the
+       * labelled set is then a sheared rectangle.  Undo the shear: first k in 0,1,-1,2,-2,3,-3 for
+       * which (i + k*j, j) fills a cols x rows (or rows x cols) box. */
+      for (int si2 = 0; si2 < 7 && !found; ++si2) {
+        int k = SHEAR[si2];
+        int i0 = 1 << 20, i1 = -(1 << 20), j0 = 1 << 20, j1 = -(1 << 20);
+        for (int q = 0; q < nl; ++q) {
+          int ii = li[q] + k * lj[q], jj = lj[q];
+          if (ii < i0) i0 = ii;
+          if (ii > i1) i1 = ii;
+          if (jj < j0) j0 = jj;
+          if (jj > j1) j1 = jj;
+        }
+        int bw = i1 - i0 + 1, bh = j1 - j0 + 1;
+        if (bw == cols && bh == rows) { found = 1; transpose = 0; }
+        else if (bw == rows && bh == cols) { found = 1; transpose = 1; }
+        if (found) { imin = i0; jmin = j0; shear = k; }
       }
-      int bw = i1 - i0 + 1, bh = j1 - j0 + 1;
-      if (bw == cols && bh == rows) { found = 1; transpose = 0; }
-      else if (bw == rows && bh == cols) { found = 1; transpose = 1; }
-      if (found) { imin = i0; jmin = j0; shear = k; }
+    } else {
+      /* [B] round 4: MORE labels than the board has corners -- something junction-like next to the board (an object touching its
+       * border squares) continued a row or a column by a cell or two (at most GEXTRA labels more: beyond, the seed is given up).  The board is then the one fully labelled cols x rows (or
+       * rows x cols) window of the labelled set: shears in the same order; the first shear under which any window is full decides
+       * -- exactly one window: taken, the labels outside it are dropped; several (a whole extra row or column): the seed is given
+       * up.  (bbox == board and L == need above is the same statement for a set without extras.) */
+      for (int si2 = 0; si2 < 7 && !found; ++si2) {
+        int k = SHEAR[si2];
+        int i0 = 1 << 20, i1 = -(1 << 20), j0 = 1 << 20, j1 = -(1 << 20);
+        for (int q = 0; q < nl; ++q) {
+          int ii = li[q] + k * lj[q], jj = lj[q];
+          if (ii < i0) i0 = ii;
+          if (ii > i1) i1 = ii;
+          if (jj < j0) j0 = jj;
+          if (jj > j1) j1 = jj;
+        }
+        int wins = 0, wi = 0, wj = 0, wt = 0;
+        for (int tr = 0; tr < (cols == rows ? 1 : 2); ++tr) {
+          int cw = tr ? rows : cols, ch = tr ? cols : rows;
+          for (int a0 = i0; a0 + cw - 1 <= i1; ++a0)
+            for (int b0 = j0; b0 + ch - 1 <= j1; ++b0) {
+              int full = 1;
+              for (int b = 0; b < ch && full; ++b)
+                for (int a = 0; a < cw; ++a) {
+                  int jj = b0 + b, oi = a0 + a - k * jj;
+                  if (oi < -GM || oi > GM || LAB(oi, jj) < 0) { full = 0; break; }
+                }
+              if (full) { if (!wins) { wi = a0; wj = b0; wt = tr; } ++wins; }
+            }
+        }
+        if (wins == 1) { found = 1; transpose = wt; imin = wi; jmin = wj; shear = k; }
+        else if (wins > 1) break;
+      }
     }
     if (!found) continue;
     /* bbox area == need and L == need and the shear is a bijection => every cell is filled */
     int32_t tmp[GMAXPTS];
     for (int q = 0; q < nl; ++q) {
       int a = li[q] + shear * lj[q] - imin, b = lj[q] - jmin;   /* a along the box width */
+      if (a < 0 || b < 0 || a >= (transpose ? rows : cols) || b >= (transpose ? cols : rows)) continue;   /* a label outside the window (L > need) */
       int c = transpose ? b : a, r = transpose ? a : b;
       tmp[r * cols + c] = lk[q];
     }

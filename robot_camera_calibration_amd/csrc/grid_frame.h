@@ -16,6 +16,7 @@
 #define GM 24
 #define GW (2 * GM + 1)
 #define GBOARD 16
+#define GEXTRA 8            // a6: labels beyond cols x rows that the window rule takes (round 4)
 
 __constant__ int8_t c_ring16[16][2] = {
   { 5, 0}, { 5, 2}, { 4, 4}, { 2, 5}, { 0, 5}, {-2, 5}, {-4, 4}, {-5, 2},
@@ -476,14 +477,15 @@ __device__ __forceinline__ bool lattice_board(grid_smem& sm, const int f, const 
       }
     }
     GTRACE(2); GTRACE_VAL(7, si * 1000 + L);
-    if (L != need) continue;
+    if (L < need || L > need + GEXTRA) continue;
     // un-shear: first k in 0,1,-1,2,-2,3,-3 whose (i + k*j, j) box is cols x rows or rows x cols.  The labelled cells are
     // the cells of the used points (L of them), each in the lane that holds the point.
     int found = 0, transpose = 0, imin = 0, jmin = 0, shear = 0;
     int j0 = 1 << 20, j1 = -(1 << 20);
 #pragma unroll
     for (int q = 0; q < J; ++q) if ((usedm >> q) & 1u) { const int jj = (cellr[q] >> 8) - GM; j0 = min(j0, jj); j1 = max(j1, jj); }
-    j0 = wave_min_i32(j0); j1 = wave_max_i32(j1);
+    j0 = uni(wave_min_i32(j0)); j1 = uni(wave_max_i32(j1));
+    if (L > need) __syncthreads();        // the label table as lane 0 wrote it, for every lane
 #pragma unroll 1
     for (int t = 0; t < 7 && !found; ++t) {
       const int k = (t == 0) ? 0 : ((t & 1) ? (t + 1) / 2 : -(t / 2));
@@ -495,16 +497,41 @@ __device__ __forceinline__ bool lattice_board(grid_smem& sm, const int f, const 
         i0 = min(i0, is); i1 = max(i1, is);
       }
       i0 = uni(wave_min_i32(i0)); i1 = uni(wave_max_i32(i1));
-      const int bw = i1 - i0 + 1, bh = uni(j1) - uni(j0) + 1;
-      if (bw == cols && bh == rows) { found = 1; transpose = 0; }
-      else if (bw == rows && bh == cols) { found = 1; transpose = 1; }
-      if (found) { imin = i0; jmin = uni(j0); shear = k; }
+      if (L == need) {
+        const int bw = i1 - i0 + 1, bh = j1 - j0 + 1;
+        if (bw == cols && bh == rows) { found = 1; transpose = 0; }
+        else if (bw == rows && bh == cols) { found = 1; transpose = 1; }
+        if (found) { imin = i0; jmin = j0; shear = k; }
+      } else {
+        // round 4: up to GEXTRA labels more than the board has corners (something junction-like next to the board continued a row or
+        // a column): the board is the ONE fully labelled cols x rows (or rows x cols) window under the first shear that has any --
+        // several: the seed is given up.  Lane c tests cell c of the window; rare path, a handful of windows.
+        int wins = 0, wi = 0, wj = 0, wt = 0;
+        const int ntr = (cols == rows) ? 1 : 2;
+        for (int tr = 0; tr < ntr; ++tr) {
+          const int cw = tr ? rows : cols, ch = tr ? cols : rows;
+          for (int a0 = i0; a0 + cw - 1 <= i1; ++a0)
+            for (int b0 = j0; b0 + ch - 1 <= j1; ++b0) {
+              bool ok = true;
+              for (int c = lane; c < need; c += 64) {
+                const int b = c / cw, a = c - b * cw;
+                const int jj = b0 + b, oi = a0 + a - k * jj;
+                const bool in = (oi >= -GM) && (oi <= GM);
+                ok = ok && in && (sm.labp[((in ? oi : 0) + GM) * GW + (jj + GM)] >= 0);
+              }
+              if (__ballot(!ok) == 0ull) { if (!wins) { wi = a0; wj = b0; wt = tr; } ++wins; }
+            }
+        }
+        if (wins == 1) { found = 1; transpose = wt; imin = wi; jmin = wj; shear = k; }
+        else if (wins > 1) break;
+      }
     }
     if (!found) continue;
 #pragma unroll
     for (int q = 0; q < J; ++q) if ((usedm >> q) & 1u) {
       const int ii = (cellr[q] & 255) - GM, jj = (cellr[q] >> 8) - GM;
       const int a2 = ii + shear * jj - imin, bb = jj - jmin;
+      if (a2 < 0 || bb < 0 || a2 >= (transpose ? rows : cols) || bb >= (transpose ? cols : rows)) continue;     // a label outside the window (L > need)
       const int cc = transpose ? bb : a2, rr = transpose ? a2 : bb;
       sm.tmp[rr * cols + cc] = (int16_t)(lane + 64 * q);
     }

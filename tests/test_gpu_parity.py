@@ -218,6 +218,32 @@ def test_pipeline_board_found_through_second_seed_group(torch_cuda, oracle):
     assert np.abs(got[:, None, :] - gt[None, :, :]).max(2).min(1).max() < 0.3          # every corner within 0.3 px of a projected one
 
 
+def test_pipeline_objects_touching_the_board_border(torch_cuda, oracle):
+    """round 4, a6 on the device: the four scenes of tests/test_oracle_kat.py::test_board_with_objects_touching_its_border (the growth
+    labels 49-51 cells; the board is the one fully labelled 8 x 6 window) -- every stage against the oracle, all four found, with the
+    corners of the scenes without the rectangles."""
+    from tests.util import clutter_bgr
+    torch = torch_cuda
+    W, H = 1280, 720
+    cfg = _make(None, w=W, h=H, B=8)
+    K = np.array(list(cfg.K))
+    imgs = []
+    for seed in (1, 3, 6, 7):
+        sp = abi.default_synth_params(seed=seed)
+        pose = synth.sample_poses(1, cfg, seed=seed, z_range=(1.2, 2.8))[0]
+        img = np.asarray(oracle.synth_render(cfg, sp, pose, 0)).reshape(H, W, 3)
+        gt = synth.project_points(synth.board_object_points(8, 6, 0.108), pose[:3], pose[3:], K)
+        imgs += [clutter_bgr(img, 5000 + 17 * seed + 200, 200, (gt[:, 0].min() - 25, gt[:, 1].min() - 25, gt[:, 0].max() + 25, gt[:, 1].max() + 25)), img]
+    frames = torch.from_numpy(np.ascontiguousarray(np.stack(imgs)).reshape(8, -1)).cuda()
+    mx, found = _check_batch(torch, oracle, cfg, frames, 8, expect_found=True)
+    det = api.Detector(cfg)
+    dets, fcs = det.detect(frames, 8)
+    det.close()
+    for q in range(4):
+        assert int(fcs[2 * q].ncorners) == 48 and int(fcs[2 * q].nkept) > int(fcs[2 * q + 1].nkept)
+        assert np.abs(np.asarray(fcs[2 * q].xy[:48]) - np.asarray(fcs[2 * q + 1].xy[:48])).max() == 0.0
+
+
 def test_pipeline_mono_raw_distortion_in_pnp(torch_cuda, oracle):
     """undistort = 0: detector on the raw image, PnP with D -- the reference's own arrangement
     (camera_pose.cpp:163 passes kdistCoeffs)"""

@@ -454,6 +454,61 @@ def test_grid_index_second_seed_group_by_score(oracle):
     assert run(50000, 50000)[0]              # equal scores: ties go to the smaller index, and the list is ordered by (y, x) -- the lattice's first row here
 
 
+def test_grid_index_takes_the_one_full_window_among_extra_labels(oracle):
+    """round 4, a6: junction-like points next to the board continue a row or a column, and the growth labels more than cols x rows
+    cells.  One to three such points: the board is the one fully labelled 8 x 6 window, found, the extras dropped.  A whole extra
+    column: two windows are full -- refused.  More than eight extra labels: refused."""
+    H = np.eye(3); H[:2, :2] *= 25; H[:2, 2] = [200, 150]; H[2, 0] = 2e-4
+    def pts(cols, rows, c0=0, r0=0):
+        out = []
+        for r in range(r0, r0 + rows):
+            for c in range(c0, c0 + cols):
+                q = H @ np.array([c, r, 1.0]); out.append(q[:2] / q[2])
+        return np.rint(np.array(out)).astype(int)
+    board = pts(8, 6)
+    def run(extra):
+        allp = np.concatenate([board, extra]) if len(extra) else board
+        order = np.lexsort((allp[:, 0], allp[:, 1]))
+        cand = np.zeros(len(allp), oracle.CAND_DT)
+        cand["x"] = allp[order, 0]; cand["y"] = allp[order, 1]; cand["score"] = 500000
+        ok, idx = oracle.grid_index(cand, 8, 6)
+        return ok, (np.stack([cand["x"][idx], cand["y"][idx]], 1) if ok else None)
+    ok0, ref = run(np.zeros((0, 2), int))
+    assert ok0
+    for extra in (pts(1, 1, 8, 2), pts(1, 2, 8, 1), pts(2, 1, 3, 6), np.concatenate([pts(1, 1, -1, 0), pts(1, 1, 8, 5), pts(1, 1, 4, -1)])):
+        ok, got = run(extra)
+        assert ok and (got == ref).all(), extra.tolist()
+    assert not run(pts(1, 6, 8, 0))[0]                    # a ninth column: 8 x 6 fits twice
+    assert not run(pts(8, 1, 0, 6))[0]                    # a seventh row
+    assert not run(np.concatenate([pts(1, 5, 8, 0), pts(5, 1, 0, 6)]))[0]        # ten extra labels: beyond what the rule takes
+
+
+def test_board_with_objects_touching_its_border(oracle):
+    """the same through the whole path: rectangles pasted right up to 25 px from the outermost inner corners -- onto the board's border
+    squares -- leave every inner corner intact but put junctions where a row or column would continue.  Found, with the corners of the
+    plain scene (rounds 1-3 and the first half of round 4: 4-6 of 12 such scenes)."""
+    from tests.util import clutter_bgr
+    W, H = 1280, 720
+    cfg = oracle.default_config()
+    abi.set_geometry(cfg, W, H, abi.RCC_PIX_BGR8)
+    ctx = oracle.Context(cfg)
+    K = np.array(list(cfg.K))
+    ok = 0
+    for seed in (1, 3, 6, 7):
+        sp = abi.default_synth_params(seed=seed)
+        pose = synth.sample_poses(1, cfg, seed=seed, z_range=(1.2, 2.8))[0]
+        img = oracle.synth_render(cfg, sp, pose, 0)
+        gt = synth.project_points(synth.board_object_points(8, 6, 0.108), pose[:3], pose[3:], K)
+        n0, det0, fc0 = ctx.detect(img, 0)
+        c = clutter_bgr(img, 5000 + 17 * seed + 200, 200, (gt[:, 0].min() - 25, gt[:, 1].min() - 25, gt[:, 0].max() + 25, gt[:, 1].max() + 25))
+        n, det, fc = ctx.detect(c, 0)
+        assert n0 == 1 and n == 1 and fc.ncorners == 48
+        assert np.abs(np.array(fc.xy[:48]) - np.array(fc0.xy[:48])).max() == 0.0
+        ok += 1
+    assert ok == 4
+    ctx.close()
+
+
 def test_board_object_points_follow_reference_convention():
     """x right, y up, z = 0, origin at the centre (camera_pose.cpp:158-161); index = row*cols+col"""
     o = synth.board_object_points(8, 6, 0.108)
