@@ -1,26 +1,34 @@
 """Study (oracle only, CPU): how many of 12 boards (1280x720, z 1.2-2.8 m) the lattice stage finds among `count` random rectangles that
-keep 80 px from the board.  With the centroid seeds alone (the oracle at commit 1eef71c, before the second seed group): 12 / 12 / 11 / 10 /
-9 / 9 at 200 / 400 / 600 / 800 / 1000 / 1400 rectangles; with the second group (this tree): 12 of 12 at every level, no wrong board.
-usage: python scratch/seed_study.py"""
+keep KO px (environment, default 80) from the outermost inner corners -- KO <= 40 puts rectangles onto the board's border squares.
+Found = the 48 corners of the scene without the rectangles, bit for bit.
+  KO 80, centroid seeds alone (the oracle at commit 1eef71c): 12 / 12 / 11 / 10 / 9 / 9 at 200 / 400 / 600 / 800 / 1000 / 1400 rectangles;
+         with the second seed group: 12 of 12 at every level.
+  KO 40 / 25 / 12 at 200 / 600 / 1000 rectangles, growth demanding exactly cols x rows labels (commit 8d8d5b0, before the window rule):
+         11 8 5 / 6 4 4 / 7 2 1 of 12 -- in every lost scene all 48 corners were validated and the growth had labelled 49-51 cells;
+         with the window rule: 12 of 12 in all nine cells.
+  KO 0 (rectangles up to and over the outermost corners themselves): corners move or are replaced -- 9 / 3 / 3 of 12 bit-identical,
+         most of the others found with sub-pixel shifts, a few with one corner taken from the clutter (5.7 and 22 px off): occlusion.
+usage: KO=25 python scratch/seed_study.py"""
 import os, sys, numpy as np
 sys.path.insert(0, '/root/repo')
 from oracle import orc_py as oracle
 from robot_camera_calibration_amd import abi, synth
 from tests.util import clutter_bgr
 W, H = 1280, 720
+KO = int(os.environ.get("KO", "80"))
 cfg = oracle.default_config()
 abi.set_geometry(cfg, W, H, abi.RCC_PIX_BGR8)
 ctx = oracle.Context(cfg)
 K = np.array(list(cfg.K))
 res = {}
-for count in (200, 400, 600, 800, 1000, 1400):
+for count in (200, 600, 1000):
     ok = tot = over = 0
     for seed in range(12):
         sp = abi.default_synth_params(seed=seed)
         pose = synth.sample_poses(1, cfg, seed=seed, z_range=(1.2, 2.8))[0]
         img = oracle.synth_render(cfg, sp, pose, 0)
         gt = synth.project_points(synth.board_object_points(8, 6, 0.108), pose[:3], pose[3:], K)
-        ko = (gt[:, 0].min() - 80, gt[:, 1].min() - 80, gt[:, 0].max() + 80, gt[:, 1].max() + 80)
+        ko = (gt[:, 0].min() - KO, gt[:, 1].min() - KO, gt[:, 0].max() + KO, gt[:, 1].max() + KO)
         n0, det0, fc0 = ctx.detect(img, 0)
         if n0 != 1: continue
         c = clutter_bgr(img, 5000 + 17 * seed + count, count, ko)
