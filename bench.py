@@ -811,6 +811,7 @@ def main():
             "what": "threshold+corner pass as rcc_detect_batch launches it (binary image kept as a 1-byte-per-4x4-tile threshold map)",
             "achieved": algc / (ms_c * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": algc / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_2px": alg2 / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_of_guide_copy_6290": algc / (ms_c * 1e-3) / 1e9 / 6290.0,      # both peaks -- the specification's 8 TB/s (frac) and the guide's measured float4 copy
             "alg_bytes_per_launch": algc, "alg_bytes_2px_per_launch": alg2, "ms_per_launch": ms_c, "frames_per_launch": B,
             "ms_per_launch_source": ("HIP events around the launch inside each of the %d timed steps (mean)" % len(dense_in_step)) if dense_in_step and min(dense_in_step) > 0 else "back-to-back launches (no in-step events in this mode)",
             "ms_per_launch_back_to_back": ms_b2b, "frac_back_to_back": algc / (ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_2px_back_to_back": alg2 / (ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -827,6 +828,8 @@ def main():
         tr_i, src_i = traffic_of("traffic_ingest.json")
         out["roofline_ingest"] = {"bound": "hbm", "kernel": "k_ingest_staged<3> (undistort + grey)", "achieved": algi / (msi * 1e-3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algi / (msi * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "frac_of_guide_copy_6290": algi / (msi * 1e-3) / 1e9 / 6290.0,
+                                  "frac_of_own_copy": ((alg2 / (copy_ms * 1e-3)) and (algi / (msi * 1e-3)) / (alg2 / (copy_ms * 1e-3))) if copy_ms else None,
                                   "traffic": tr_i, "traffic_source": src_i, "alg_bytes_per_launch": algi, "ms_per_launch": msi}
         # the whole step against HBM: SURVEY 8(d)'s algorithmic bytes of the three passes over pixels (ingest 4 px, threshold + corner
         # pass px + px / 16 as the step runs it; the tail's bytes are negligible) over the step's time
