@@ -244,6 +244,26 @@ def test_pipeline_objects_touching_the_board_border(torch_cuda, oracle):
         assert np.abs(np.asarray(fcs[2 * q].xy[:48]) - np.asarray(fcs[2 * q + 1].xy[:48])).max() == 0.0
 
 
+@pytest.mark.parametrize("cols,rows,square,z", [(5, 4, 0.15, (1.0, 1.8)), (7, 7, 0.10, (1.0, 1.8)), (11, 8, 0.07, (1.0, 1.8)), (16, 12, 0.045, (1.0, 1.6)), (3, 3, 0.2, (1.2, 2.2))],
+                         ids=["5x4", "7x7", "11x8", "16x12", "3x3"])
+def test_pipeline_other_board_geometries(torch_cuda, oracle, cols, rows, square, z):
+    """boards other than the reference's 8 x 6 (README.md:57): fewer corners than a wave has lanes, a square board (the window and
+    un-shear rules have one orientation to try), more than 64 corners (the lattice stage's four-register form, pose sums over several
+    points per lane) and the largest the configuration takes per side -- every stage against the oracle, every board found"""
+    torch = torch_cuda
+    def mod(c):
+        c.board_cols, c.board_rows, c.board_square = cols, rows, square
+    cfg = _make(mod, w=1280, h=720, B=6)
+    det = api.Detector(cfg)
+    sp = abi.default_synth_params(cols=cols, rows=rows, square=square, seed=3)
+    poses = synth.sample_poses(6, cfg, seed=11, z_range=z)
+    frames = torch.empty((6, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    det.synth_render(sp, poses, frames)
+    det.close()
+    mx, found = _check_batch(torch, oracle, cfg, frames, 6, expect_found=True)
+    print("board %dx%d: max diffs %s" % (cols, rows, mx))
+
+
 def test_pipeline_mono_raw_distortion_in_pnp(torch_cuda, oracle):
     """undistort = 0: detector on the raw image, PnP with D -- the reference's own arrangement
     (camera_pose.cpp:163 passes kdistCoeffs)"""
