@@ -83,7 +83,7 @@ while time.time() - t0 < budget:
         else:
             if rng.random() < 0.3:          # boards other than 8 x 6: down to 3 x 3, beyond 64 corners, square ones
                 cfg.board_cols, cfg.board_rows = int(rng.integers(3, 14)), int(rng.integers(3, 10))
-                cfg.board_square = float(0.9 / (cfg.board_cols + 1))
+                cfg.board_square = float(min(0.9 / (cfg.board_cols + 1), 0.65 / (cfg.board_rows + 1)))
                 sp.board_cols, sp.board_rows, sp.board_square = cfg.board_cols, cfg.board_rows, cfg.board_square
                 desc.update(board=(cfg.board_cols, cfg.board_rows))
             det = api.Detector(cfg)
