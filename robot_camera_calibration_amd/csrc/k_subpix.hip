@@ -27,24 +27,11 @@ __constant__ int8_t c_ring11[16][2] = {
   {-11, 0}, {-10,-4}, {-8,-8}, {-4,-10}, { 0,-11}, { 4,-10}, { 8,-8}, {10,-4}
 };
 
-template <bool FID>       // FID: tag scenes (the convex-black-corner test in front of the refinement, waves walk the candidate list)
-__global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
-                                               const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
-                                               rcc_subpix_params sp, const rcc_subpix_lane* __restrict__ tab, int kstride,
-                                               double* __restrict__ pre_xy, int gate_contrast /* min_contrast of the gate in front of the refinement; < 0: no gate (board scenes) */, int qstep)
-{
-  __shared__ double S[SP_MAXP * SP_MAXP];
-  const int f = blockIdx.y;
-  const int np = npre[f];
-  if ((int)blockIdx.x >= np) return;
-  const int lane = threadIdx.x;
-  const uint8_t* g = grey + (size_t)f * w * h;
-  // Board scenes: is candidate q worth refining?  The 36 L-shaped corners on the outline of a 9 x 7-square board took 42 % of this
-  // stage's iterations only to be rejected by a4.3, and a cluttered scene brings hundreds of such candidates.  Lanes 0..15 read the
-  // radius-11 ring around the candidate's pixel (a Harris maximum sits up to ~3 px off its junction, 6.5 px under heavy blur: the
-  // ring still encloses it); fewer than four transitions against the ring's own mid level, or a ring that does not span
-  // min_contrast: not a junction -- the wave writes (-1, -1), which a4.3 rejects.  A ring that leaves the image passes.
-  auto gated = [&](const int q) -> bool {
+// a5's gate for board scenes as a function of its own -- NOT inlined on purpose: inlined into the candidate loop it raised the kernel from 78
+// to 94 registers (five waves per SIMD instead of six: 0.175 -> 0.195 ms per 1024 frames, profiles r04_b / r04_c); a call costs a few
+// dozen cycles per candidate.  Returns true (and writes (-1, -1)) when candidate q of frame f cannot be a junction.
+template <bool INL>
+__device__ __forceinline__ bool subpix_gate_body(const uint8_t* g, const rcc_cand* pre, double* pre_xy, int f, int kstride, int w, int h, int gate_contrast, int lane, const int q) {
     const rcc_cand c0 = pre[(size_t)f * kstride + q];
     const int xi = c0.x, yi = c0.y;
     if (!(xi >= 11 && yi >= 11 && xi < w - 11 && yi < h - 11)) return false;      // wave-uniform
@@ -62,13 +49,37 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
       pre_xy[((size_t)f * kstride + q) * 2 + 1] = -1.0;
     }
     return true;
-  };
-  // a wave whose only candidate is gated retires before it has loaded its tables (the common case: a board frame's list is
-  // shorter than the grid is wide)
-  bool first_passed = false;
-  if (!FID && gate_contrast >= 0 && (int)blockIdx.x + qstep >= np) {
-    if (gated((int)blockIdx.x)) return;
-    first_passed = true;
+}
+__device__ __attribute__((noinline)) bool subpix_gated(const uint8_t* g, const rcc_cand* pre, double* pre_xy, int f, int kstride, int w, int h, int gate_contrast, int lane, const int q)
+{
+  return subpix_gate_body<false>(g, pre, pre_xy, f, kstride, w, h, gate_contrast, lane, q);
+}
+
+template <bool FID>       // FID: tag scenes (the convex-black-corner test in front of the refinement, waves walk the candidate list)
+__global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey, int w, int h,
+                                               const rcc_cand* __restrict__ pre, const int32_t* __restrict__ npre,
+                                               rcc_subpix_params sp, const rcc_subpix_lane* __restrict__ tab, int kstride,
+                                               double* __restrict__ pre_xy, int gate_contrast /* min_contrast of the gate in front of the refinement; < 0: no gate (board scenes) */, int qstep)
+{
+  __shared__ double S[SP_MAXP * SP_MAXP];
+  const int f = blockIdx.y;
+  const int np = npre[f];
+  if ((int)blockIdx.x >= np) return;
+  const int lane = threadIdx.x;
+  const uint8_t* g = grey + (size_t)f * w * h;
+  // Board scenes: is candidate q worth refining?  The 36 L-shaped corners on the outline of a 9 x 7-square board took 42 % of this
+  // stage's iterations only to be rejected by a4.3, and a cluttered scene brings hundreds of such candidates.  Lanes 0..15 read the
+  // radius-11 ring around the candidate's pixel (a Harris maximum sits up to ~3 px off its junction, 6.5 px under heavy blur: the
+  // ring still encloses it); fewer than four transitions against the ring's own mid level, or a ring that does not span
+  // min_contrast: not a junction -- the wave writes (-1, -1), which a4.3 rejects.  A ring that leaves the image passes.
+  auto gated = [&](const int q) -> bool { return subpix_gated(g, pre, pre_xy, f, kstride, w, h, gate_contrast, lane, q); };
+  // the wave's FIRST candidate is tested in line, in front of everything (nothing else is live yet): in a board frame without clutter
+  // it is the only one, and most waves end here or go straight on to their one refinement; only the walk over a longer list calls
+  const bool gate_on = !FID && gate_contrast >= 0;
+  bool first_gated = false;
+  if (gate_on) {
+    first_gated = subpix_gate_body<true>(g, pre, pre_xy, f, kstride, w, h, gate_contrast, lane, (int)blockIdx.x);
+    if (first_gated && (int)blockIdx.x + qstep >= np) return;
   }
   const int win = sp.win;
   const int ww = 2 * win + 1, pw = 2 * win + 3;
@@ -76,21 +87,32 @@ __global__ __launch_bounds__(64) void k_subpix(const uint8_t* __restrict__ grey,
   // idx = lane + 64 t < pw^2 and gradient samples k = lane + 64 t < ww^2, tabulated at rcc_create -- no integer division here
   constexpr int PT = RCC_SP_PT, GT = RCC_SP_GT;
   static_assert(PT == (SP_MAXP * SP_MAXP + 63) / 64 && GT == ((2 * SP_MAXW + 1) * (2 * SP_MAXW + 1) + 63) / 64, "table shape");
-  const rcc_subpix_lane T = tab[lane];
   int poff[PT];            // (i - win - 1) * w + (j - win - 1): offset of the sample's top-left tap from (iy, ix)
   int goff[GT];            // (i + 1) * pw + (j + 1): centre of the gradient stencil in S
   double gm[GT], gpx[GT], gpy[GT];
+  auto load_tables = [&](const int tl) {
+    const rcc_subpix_lane T = tab[tl];
 #pragma unroll
-  for (int t = 0; t < PT; ++t) poff[t] = T.poff[t];
+    for (int t = 0; t < PT; ++t) poff[t] = T.poff[t];
 #pragma unroll
-  for (int t = 0; t < GT; ++t) { goff[t] = T.goff[t]; gm[t] = T.gm[t]; gpx[t] = (double)T.gpx[t]; gpy[t] = (double)T.gpy[t]; }
+    for (int t = 0; t < GT; ++t) { goff[t] = T.goff[t]; gm[t] = T.gm[t]; gpx[t] = (double)T.gpx[t]; gpy[t] = (double)T.gpy[t]; }
+  };
+  // Tag scenes load the tables once, in front of the walk over the list.  Board scenes load them INSIDE the loop, behind the gate: a
+  // wave whose candidate is gated (the common case: 36 outline candidates of ~ 85 per frame) retires without them; the asm keeps the
+  // compiler from hoisting the loop-invariant load in front of the gate.
+  if (FID) load_tables(lane);
   // candidates blockIdx.x, + qstep, ... of the frame (qstep = the grid's width: one candidate per wave where the lists are
   // short; tag scenes hold ~750 candidates of up to 2048, two thirds of which leave at the test below, and a wave that finds
   // its slot unused still costs a slot for a microsecond -- there the grid is narrower than the list and a wave walks it)
   constexpr bool fid = FID;
   const int per_pass = fid ? 4 : 1;
   for (int q0 = blockIdx.x; q0 < np; q0 += per_pass * qstep) {
-  if (!FID && gate_contrast >= 0 && !(first_passed && q0 == (int)blockIdx.x) && gated(q0)) continue;
+  if (!FID) {
+    if (gate_on && (q0 == (int)blockIdx.x ? first_gated : gated(q0))) continue;
+    int tl = lane;
+    asm volatile("" : "+v"(tl));
+    load_tables(tl);
+  }
   unsigned refine_m = 1u;                  // bit k: candidate q0 + k * qstep is refined
   int cgx = 0, cgy = 0;                    // fid: the candidate of this lane's group of 16
   if (fid) {
