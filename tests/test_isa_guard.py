@@ -216,3 +216,37 @@ def test_counted_wait_invariant_holds_in_the_compiled_wave_kernel(wave_listing):
         assert any(t.startswith("s_waitcnt") and "vmcnt(0)" in t for t in ins[dmas[0]:waits[0]]), "%s: the prologue no longer waits outright" % name
         ends = [i for i, t in enumerate(ins) if t.startswith("s_endpgm")]
         assert ends and any(any(u.startswith("s_waitcnt") and "vmcnt(0)" in u for u in ins[max(0, e - 8):e]) for e in ends)
+
+
+# ---- register budgets of the step's kernels (round 4) ---------------------------------------------------------------------------
+# A kernel's wave slots per SIMD follow from its register count (512 / allocation granule of 8), and two of the step's kernels are
+# bound by how many ready waves a SIMD holds.  Round 4 lost one wave per SIMD in k_subpix without anyone noticing (78 -> 94
+# registers when the gate moved into the candidate loop: 0.175 -> 0.195 ms, found in the rocprof summary of the NEXT profile set).
+# This compiles the kernels for gfx950 (no GPU needed) and holds each to the occupancy the measurements in DESIGN.md section 5 were
+# taken at.
+BUDGETS = [("k_subpix.hip", r"_Z8k_subpixILb0E", 80, 6, "board-scene sub-pixel stage: six waves per SIMD"),
+           ("k_dense_wave.hip", r"_Z12k_dense_waveILi0ELi1E", 80, 6, "threshold + corner pass of the step: six waves per SIMD (amdgpu_waves_per_eu)"),
+           ("k_ingest.hip", r"_Z15k_ingest_stagedILi3ELb0ELi16E", 64, 8, "ingest pass: four 512-thread workgroups per CU")]
+
+
+@pytest.mark.parametrize("src,symbol,max_vgprs,min_occupancy,what", BUDGETS, ids=[b[0] for b in BUDGETS])
+def test_register_budget_of_step_kernels(tmp_path, src, symbol, max_vgprs, min_occupancy, what):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    out = str(tmp_path / (src + ".s"))
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S", "--cuda-device-only",
+                           "-I", os.path.join(ROOT, "include"), "-o", out, os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
+    lines = open(out).read().split("\n")
+    start = [i for i, l in enumerate(lines) if re.match(r"^%s\S*:" % symbol, l)]
+    assert start, "kernel %s not found in the listing of %s" % (symbol, src)
+    nv = occ = scratch = None
+    for l in lines[start[0]:]:
+        m = re.match(r"^; NumVgprs: (\d+)", l)
+        if m and nv is None: nv = int(m.group(1))
+        m = re.match(r"^; ScratchSize: (\d+)", l)
+        if m and scratch is None: scratch = int(m.group(1))
+        m = re.match(r"^; Occupancy: (\d+)", l)
+        if m:
+            occ = int(m.group(1)); break
+    assert nv is not None and occ is not None, "no register summary behind %s" % symbol
+    assert nv <= max_vgprs and occ >= min_occupancy and scratch == 0, "%s: %d registers, occupancy %d, scratch %s (%s)" % (symbol, nv, occ, scratch, what)
