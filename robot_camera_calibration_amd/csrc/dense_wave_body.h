@@ -35,13 +35,28 @@ __device__ __forceinline__ void dense_wave_body(const uint8_t* __restrict__ grey
   // workgroup -> job, as the band kernel deals them (an XCD takes chunks of consecutive frames along a diagonal); the
   // windows of a band segment are consecutive jobs of one XCD, so the halo columns they share meet in its L2
   const int wpj = (GANG > 1) ? 1 : nwin;                       // jobs (workgroups) per band segment
-  const int jpf = nbands * nseg * wpj, cj = fchunk * jpf, k = (int)(vblock >> 3);
-  const int grp = k / cj, r = k - grp * cj;
-  const int f = (8 * grp + (((int)(vblock & 7u) - grp) & 7)) * fchunk + r / jpf;
+  const int k = (int)(vblock >> 3);
+  int f, wv, band, seg;
+  if (fchunk > 0) {
+    const int jpf = nbands * nseg * wpj, cj = fchunk * jpf;
+    const int grp = k / cj, r = k - grp * cj;
+    f = (8 * grp + (((int)(vblock & 7u) - grp) & 7)) * fchunk + r / jpf;
+    const int jr = r % jpf;
+    wv = (GANG > 1) ? wib : jr % wpj;
+    band = (jr / wpj) % nbands; seg = jr / (wpj * nbands);
+  } else {
+    // fchunk <= 0: the SEGMENT-interleaved deal.  The unit is a band segment of a frame (its windows stay together: they share halo
+    // columns in the XCD's L2); unit U = frame * nseg + segment, and of every eight consecutive units each XCD takes one, the
+    // assignment rotating with the group -- so an XCD sees every frame (an eighth of it) and every segment position equally often.
+    // (With whole frames per XCD the XCDs' loads are sums over 128 frames each, and the launch ends with the busiest XCD.)
+    const int wpu = nbands * wpj;
+    const int u = k / wpu, jr = k - u * wpu;
+    const long long U = 8LL * u + (long long)((((int)(vblock & 7u)) + u) & 7);
+    f = (int)(U / nseg); seg = (int)(U - (long long)f * nseg);
+    wv = (GANG > 1) ? wib : jr % wpj;
+    band = jr / wpj;
+  }
   if (f >= nframes) return;
-  const int jr = r % jpf;
-  const int wv = (GANG > 1) ? wib : jr % wpj;
-  const int band = (jr / wpj) % nbands, seg = jr / (wpj * nbands);
   if (GANG > 1 && wv >= nwin) return;
   const int lane = threadIdx.x & 63;
   const int th = h >> 2;

@@ -20,6 +20,7 @@
 // 128-byte lines, one dword per lane and row -- built and measured: 1.55-1.64 ms per 1024 x 1080p with non-temporal
 // stores, 1.35 ms with cached ones, against the band kernel's 0.90-0.92 (scratch/membench3.hip had the stores alone at
 // 0.58 ms against 0.36 ms for whole lines).
+#include <cstdlib>
 #include "dense_wave_body.h"
 
 template <int PRIO, int GANG>
@@ -66,6 +67,16 @@ void rcc_dense_wave_plan(const rcc_handle* h, int nframes, rcc_wave_plan* p)
   p->seg_tiles = (th + nseg - 1) / nseg;
   p->nseg = (th + p->seg_tiles - 1) / p->seg_tiles;
   p->njobs = (long long)p->nbands * p->nseg * p->nwin * ((nframes + 8 * p->fchunk - 1) / (8 * p->fchunk)) * 8 * p->fchunk;
+#ifdef RCC_EXPERIMENTS
+  static const int deal = getenv("RCC_DENSE_DEAL") ? atoi(getenv("RCC_DENSE_DEAL")) : 0;
+#else
+  const int deal = 0;
+#endif
+  if (deal == 1) {            // segment-interleaved deal (dense_wave_body.h): units of one band segment, eight per group
+    p->fchunk = 0;
+    const long long units = (long long)nframes * p->nseg;
+    p->njobs = ((units + 7) / 8) * 8 * (long long)p->nbands * p->nwin;
+  }
 }
 
 hipError_t rcc_launch_dense_wave(rcc_handle* h, const uint8_t* d_grey, int nframes, rcc_cand* d_cand, int32_t* d_cand_count, hipStream_t s)
