@@ -47,6 +47,7 @@ def parse(argv=None):
     ap.add_argument("--roofline-reps", type=int, default=5)
     ap.add_argument("--sync-steps", action="store_true", help="time K synchronous detect() calls instead of the submit/collect stream of K batches")
     ap.add_argument("--keep-gc", action="store_true", help="A/B: leave Python's cyclic garbage collector running inside the timed regions")
+    ap.add_argument("--tail-overlap", type=int, default=0, help="experiments library: lattice + pose kernel of a streamed batch under the next batch's ingest pass (1)")
     ap.add_argument("--sync-first", action="store_true", help="A/B of the order: run the synchronous comparison region BEFORE the streamed region that defines `value`")
     ap.add_argument("--pipeline", type=int, default=1, help="chunks of the detector's two-stream pipeline per step (1: single pass)")
     ap.add_argument("--fiducials", default="", help="BASELINE.json configs[4]-style run: GXxGY planar grid of square fiducials per frame, e.g. 6x4")
@@ -608,6 +609,8 @@ def main():
     det.set_pipeline(a.pipeline)
     det.set_dense_variant(a.dense_variant)
     det.set_ingest_variant(a.ingest_variant)
+    if a.tail_overlap:
+        det.set_tail_overlap(a.tail_overlap)
     B = a.batch
     px = a.width * a.height
 

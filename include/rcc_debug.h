@@ -109,6 +109,10 @@ int rcc_debug_overlap(rcc_handle* h, const void* d_frames, int32_t nframes, void
 /* experiment: the wave-per-window threshold + corner pass reads the grey rows of frame (f mod m) -- a working set small enough
  * to stay in the Infinity Cache; m = 0: off.  Results are then those of the wrong frames. */
 int rcc_set_dense_fmod(rcc_handle* h, int32_t m);
+/* experiment (round 4): mode 1 -- a streamed board batch's lattice + pose kernel runs on a stream of the handle's own, under the next
+ * batch's ingest pass; 0 off.  Device-resident batches without corner tables and
+ * without record tables only.  Result: DESIGN.md section 5, "Measured, not kept". */
+int rcc_set_tail_overlap(rcc_handle* h, int32_t mode);
 /* experiment (scratch/t_grid_trace.py): per-frame phase time stamps of k_grid_pnp -- d_buf: nframes x 24 int64 (device), slots
  * 0 start, 1 seeds done, 3 growth starts, 2 growth done, 5 lattice done, 6 pose done (10-ns ticks), 7 = seed attempt * 1000 + labels,
  * 8 homography starts, 9 DLT done, 10 refinement done, 11 homography returned, 12 initial pose done, 13 = refinement iterations,

@@ -145,7 +145,7 @@ DEBUG_EXPORTED_SYMBOLS = (
     "rcc_debug_calib_copy", "rcc_debug_fetch_lists", "rcc_debug_fetch_images", "rcc_debug_pnp_probe",
 )
 # only in librcc_hip_exp.so (make EXPERIMENTS=1): measurement-only kernel forms and one-off experiments; never in the product library
-EXPERIMENT_ONLY_SYMBOLS = ("rcc_set_dense_gang", "rcc_debug_overlap", "rcc_set_dense_fmod", "rcc_debug_grid_trace")
+EXPERIMENT_ONLY_SYMBOLS = ("rcc_set_dense_gang", "rcc_debug_overlap", "rcc_set_dense_fmod", "rcc_debug_grid_trace", "rcc_set_tail_overlap")
 # include/rcc_dist.h (librcc_dist.so: the RCCL all-gather of the record tables for non-Python hosts)
 DIST_EXPORTED_SYMBOLS = ("rcc_dist_unique_id", "rcc_dist_create", "rcc_dist_destroy", "rcc_dist_rank", "rcc_dist_world",
                          "rcc_dist_allgather_records", "rcc_dist_last_error", "rcc_dist_last_create_error")
@@ -394,6 +394,15 @@ class Detector:
         if not hasattr(self._L, "rcc_set_dense_gang"):
             raise RuntimeError("rcc_set_dense_gang exists only in librcc_hip_exp.so (make -C csrc EXPERIMENTS=1; RCC_LIBRARY selects it)")
         return self._L.rcc_set_dense_gang(self._h, int(sync_rows), int(segments))
+
+    def set_tail_overlap(self, mode):
+        """experiments library only: streamed board batches run their lattice + pose kernel on a stream of its own, under the next
+        batch's ingest pass (1 on, 0 off)"""
+        if not hasattr(self._L, "rcc_set_tail_overlap"):
+            raise RuntimeError("rcc_set_tail_overlap exists only in librcc_hip_exp.so")
+        self._L.rcc_set_tail_overlap.argtypes = [C.c_void_p, C.c_int]
+        self._L.rcc_set_tail_overlap.restype = C.c_int
+        return self._chk(self._L.rcc_set_tail_overlap(self._h, int(mode)), "rcc_set_tail_overlap")
 
     def set_host_chunk(self, frames_per_chunk):
         """host-resident input: frames per chunk of the copy / compute pipeline (0 automatic, < 0 one copy then the kernels)"""

@@ -167,10 +167,10 @@ __global__ __launch_bounds__(64) void k_pnp_board_wave(const rcc_frame_corners* 
 // a6 + a7 of one frame in one wavefront: lattice indexing of the validated corners (grid_frame.h), then the pose from the
 // lattice it leaves in LDS.  Both stages are single dependency chains per frame; run as two kernels the second waits for the
 // slowest frame of the first.  (a4.3, the validation, is a launch of its own: k_validate, one candidate per thread.)
-__global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* __restrict__ kept, const double* __restrict__ kept_xy,
-                                                 int cols, int rows, rcc_frame_corners* __restrict__ fc,
-                                                 const double* __restrict__ board_obj, double square, int board_id, int reference_mode,
-                                                 rcc_cam cam, rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
+__device__ __forceinline__ void grid_pnp_frame(int w, int h, const rcc_cand* __restrict__ kept, const double* __restrict__ kept_xy,
+                                               int cols, int rows, rcc_frame_corners* __restrict__ fc,
+                                               const double* __restrict__ board_obj, double square, int board_id, int reference_mode,
+                                               const rcc_cam& cam, rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
 {
   __shared__ grid_smem sm;
   __shared__ double ws[rccpnp::PNP_WS];
@@ -194,6 +194,18 @@ __global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* _
   if (g_grid_trace && threadIdx.x < 8) g_grid_trace[(size_t)f * 24 + 16 + threadIdx.x] = ((long long*)(ws + 308))[threadIdx.x];
 #endif
 }
+__global__ __launch_bounds__(64) void k_grid_pnp(int w, int h, const rcc_cand* __restrict__ kept, const double* __restrict__ kept_xy,
+                                                 int cols, int rows, rcc_frame_corners* __restrict__ fc,
+                                                 const double* __restrict__ board_obj, double square, int board_id, int reference_mode,
+                                                 rcc_cam cam, rcc_detection* __restrict__ det, int32_t* __restrict__ ndet)
+{
+  grid_pnp_frame(w, h, kept, kept_xy, cols, rows, fc, board_obj, square, board_id, reference_mode, cam, det, ndet);
+}
+#ifdef RCC_EXPERIMENTS
+// experiment (rcc_set_tail_overlap): a marker the tail stream runs in front of the lattice + pose kernel (rcc_api.hip)
+__global__ void k_marker() {}
+hipError_t rcc_launch_marker(hipStream_t s) { hipLaunchKernelGGL(k_marker, dim3(1), dim3(64), 0, s); return hipGetLastError(); }
+#endif
 
 __global__ __launch_bounds__(64) void k_pnp_generic_wave(const double* __restrict__ obj, const double* __restrict__ img,
                                                          const int32_t* __restrict__ off, const int32_t* __restrict__ npts,
@@ -303,15 +315,22 @@ hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s)
 // validation, then lattice + board pose in one launch (wave per frame); same outputs as rcc_launch_grid followed by rcc_launch_pnp_board
 hipError_t rcc_launch_grid_pnp(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s)
 {
-  const rcc_config& c = h->cfg;
   if (nframes <= 0) return hipSuccess;
   hipError_t e = rcc_launch_validate(h, d_grey, d_bin, nframes, s);
   if (e != hipSuccess) return e;
+  return rcc_launch_grid_pnp_only(h, nframes, s, 0);
+}
+// the lattice + pose kernel alone (the validated lists are in place); lean: the 128-register build (experiments library)
+hipError_t rcc_launch_grid_pnp_only(rcc_handle* h, int nframes, hipStream_t s, int lean)
+{
+  const rcc_config& c = h->cfg;
+  if (nframes <= 0) return hipSuccess;
   rcc_cam cam;
   cam.fx = c.K[0]; cam.cx = c.K[2]; cam.fy = c.K[4]; cam.cy = c.K[5];
   for (int i = 0; i < 8; ++i) cam.D[i] = c.D[i];
   cam.model = h->undist ? RCC_DIST_NONE : c.dist_model;
   cam.solver = h->pnp_solver;
+  (void)lean;
   hipLaunchKernelGGL(k_grid_pnp, dim3(nframes), dim3(64), 0, s, c.width, c.height, h->d_kept, h->d_kept_xy,
                      c.board_cols, c.board_rows, h->d_fc, h->d_board_obj, c.board_square, c.board_id,
                      c.reference_mode, cam, h->d_det, h->d_ndet);

@@ -117,6 +117,8 @@ static int validate(const rcc_config* c)
 void rcc_destroy(rcc_handle* h)
 {
   if (!h) return;
+  if (h->tail_stream) { (void)hipStreamSynchronize(h->tail_stream); (void)hipStreamDestroy(h->tail_stream); }
+  for (int k = 0; k < 2; ++k) { if (h->tail_val[k]) (void)hipEventDestroy(h->tail_val[k]); if (h->tail_mark[k]) (void)hipEventDestroy(h->tail_mark[k]); if (h->tail_done[k]) (void)hipEventDestroy(h->tail_done[k]); }
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = { h->d_map, h->d_tilebox, h->d_flat, h->d_thr, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, h->d_pre, h->d_npre, h->d_pre_xy,
@@ -724,6 +726,46 @@ int rcc_detect_batch_submit(rcc_handle* h, const void* frames, int32_t nframes, 
     HIPCHK(h, rcc_launch_dense(h, h->d_grey, nframes, h->d_bin, h->d_cand, h->d_cand_count, s));
     h->want_thr = 0;
     { int rw = wait_corner_copy(h, s); if (rw != RCC_OK) return rw; }
+#ifdef RCC_EXPERIMENTS
+    // experiment (rcc_set_tail_overlap): the previous batch's lattice + pose kernel may still be running on the tail stream -- the
+    // list stage is the first kernel that writes its buffers again
+    if (h->tail_pending) { HIPCHK(h, hipStreamWaitEvent(s, h->tail_done[h->tail_pending - 1], 0)); h->tail_pending = 0; }
+    if (h->tail_overlap && !fid && h->fuse_grid_pnp && rcc_grid_pnp_applicable(h) && !h->rec_table[slot] && !corners) {
+      // S: list, sub-pixel, validation.  T (behind them): a marker, then lattice + pose, then the records to the host.  S goes on
+      // behind the MARKER only, so the next batch's ingest pass -- queued on S by the next submission -- starts when the lattice +
+      // pose kernel has just been handed to the device, and runs beside it.
+      HIPCHK(h, hipEventRecord(tev[2], s));
+      HIPCHK(h, rcc_launch_list(h, h->d_cand, h->d_cand_count, nframes, s));
+      HIPCHK(h, rcc_launch_subpix(h, h->d_grey, nframes, s));
+      HIPCHK(h, rcc_launch_validate(h, h->d_grey, h->d_bin, nframes, s));
+      HIPCHK(h, hipEventRecord(tev[3], s));
+      HIPCHK(h, hipEventRecord(h->tail_val[slot], s));
+      hipStream_t t = h->tail_stream;
+      HIPCHK(h, hipStreamWaitEvent(t, h->tail_val[slot], 0));
+      HIPCHK(h, rcc_launch_marker(t));
+      HIPCHK(h, hipEventRecord(h->tail_mark[slot], t));
+      HIPCHK(h, rcc_launch_grid_pnp_only(h, nframes, t, 0));
+      HIPCHK(h, hipEventRecord(tev[4], t));
+      rcc_detection* hd = slot ? h->h_det2 : h->h_det;
+      int32_t* hn = slot ? h->h_ndet2 : h->h_ndet;
+      HIPCHK(h, hipMemcpyAsync(hd, h->d_det, sizeof(rcc_detection) * (size_t)nframes, hipMemcpyDeviceToHost, t));
+      HIPCHK(h, hipMemcpyAsync(hn, h->d_ndet, sizeof(int32_t) * (size_t)nframes, hipMemcpyDeviceToHost, t));
+      HIPCHK(h, hipEventRecord(tev[5], t));
+      HIPCHK(h, hipEventRecord(h->sub_ev[slot], t));
+      HIPCHK(h, hipEventRecord(h->tail_done[slot], t));
+      h->tail_pending = slot + 1;
+      HIPCHK(h, hipStreamWaitEvent(s, h->tail_mark[slot], 0));
+      h->sub_has_fc[slot] = 0;
+      h->sub_t_seq[ring] = h->sub_head + 1u;
+      h->sub_t_staged[ring] = 1;
+      h->sub_t_stream[ring] = s;
+      h->sub_nframes[slot] = nframes;
+      h->sub_stream[slot] = s;
+      ++h->sub_head;
+      for (float& m : h->last_ms) m = -1.0f;
+      return RCC_OK;
+    }
+#endif
     int r = launch_targets(h, h->d_grey, h->d_bin, h->d_cand, h->d_cand_count, nframes, s, &tev[2]);
     if (r != RCC_OK) return r;
   }
@@ -987,6 +1029,24 @@ int rcc_debug_measure_clock(rcc_handle* h, int32_t waves_per_simd, float ms_targ
 }
 
 #ifdef RCC_EXPERIMENTS
+#ifdef RCC_EXPERIMENTS
+int rcc_set_tail_overlap(rcc_handle* h, int mode)
+{
+  if (!h || mode < 0 || mode > 1) return RCC_ERR_ARG;
+  if (h->sub_head != h->sub_tail) return RCC_ERR_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (mode && !h->tail_stream) {
+    HIPCHK(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(h, hipEventCreateWithFlags(&h->tail_val[k], hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->tail_mark[k], hipEventDisableTiming));
+      HIPCHK(h, hipEventCreateWithFlags(&h->tail_done[k], hipEventDisableTiming));
+    }
+  }
+  h->tail_overlap = mode;
+  return RCC_OK;
+}
+#endif
 int rcc_set_dense_fmod(rcc_handle* h, int m)
 {
   if (!h || m < 0) return RCC_ERR_ARG;

@@ -75,6 +75,10 @@ struct rcc_handle {
   int map_th;               // tile height the source boxes in d_tilebox were tabulated for (8 or 16)
   int ingest_tile8;         // rcc_set_ingest_variant(3): staged with 128 x 8 tiles even where 128 x 16 fit (A/B, tests)
   int ingest_table;         // 1 (default): use the tables; 0: recompute (A/B, tests)
+  int tail_overlap;         // experiments only (rcc_set_tail_overlap): 1 = the lattice + pose kernel of a streamed batch on its own stream, under the next batch's ingest pass
+  hipStream_t tail_stream;
+  hipEvent_t tail_val[2], tail_mark[2], tail_done[2];
+  int tail_pending;         // 1 + slot whose tail may still be running on tail_stream
   int fuse_grid_pnp;        // 1 (default): board validation / indexing and pose in one kernel (checkerboard, wave-per-board solver)
   int keep_bin;             // rcc_set_keep_binary: rcc_detect_batch writes the full binary image (default 0: the compact map)
   int want_thr;             // set by rcc_detect_batch: the dense pass may write d_thr instead of the full binary image
@@ -193,6 +197,10 @@ hipError_t rcc_launch_pnp_tags(rcc_handle* h, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_board(rcc_handle* h, int nframes, hipStream_t s);
 hipError_t rcc_launch_pnp_tags_mfma(rcc_handle* h, int nframes, rcc_cam cam, hipStream_t s);
 hipError_t rcc_launch_grid_pnp(rcc_handle* h, const uint8_t* d_grey, const uint8_t* d_bin, int nframes, hipStream_t s);
+hipError_t rcc_launch_grid_pnp_only(rcc_handle* h, int nframes, hipStream_t s, int lean);
+#ifdef RCC_EXPERIMENTS
+hipError_t rcc_launch_marker(hipStream_t s);
+#endif
 bool rcc_grid_pnp_applicable(const rcc_handle* h);
 hipError_t rcc_launch_pnp_generic(rcc_handle* h, const double* d_obj, const double* d_img,
                                   const int32_t* d_off, const int32_t* d_npts, int ntargets,
