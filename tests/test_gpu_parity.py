@@ -886,6 +886,47 @@ def test_config2_headline_full_path_1080p(torch_cuda, oracle):
     assert found >= n - 2
 
 
+def test_full_batch_properties_1080p(torch_cuda):
+    """BASELINE.json configs[1] at its full size -- 1024 frames of 1920x1080 -- through properties that need no oracle: (1) a frame's
+    records and corner table do not depend on where in the batch it sits, nor on what its neighbours are (the batch in a random
+    order gives the same records, re-ordered); (2) nor on the batch it is part of (the second half alone = the second half of the
+    whole); (3) the streamed form returns what the synchronous call returns; (4) every board is found, and every pose re-projects
+    the board onto its own corners (rms below 0.2 px: the solver's own figure, checked here against the corners it was given)."""
+    torch = torch_cuda
+    n = 1024
+    cfg = _make(w=1920, h=1080, B=n)
+    det = api.Detector(cfg)
+    sp = abi.default_synth_params()
+    poses = synth.sample_poses(n, cfg)
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    for s0 in range(0, n, 64):
+        det.synth_render(sp, poses[s0:s0 + 64], frames[s0:s0 + 64], first_index=s0)
+    torch.cuda.synchronize()
+    d0, fc0 = det.detect(frames, n)
+    assert len(d0) == n and (d0.frame == np.arange(n)).all() and (fc0.ncorners == 48).all()
+    assert float(d0.rms.max()) < 0.2
+    def body(d):            # a record without its frame index
+        a = np.array(d, copy=True)
+        a["frame"] = 0
+        return a
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(n)
+    shuffled = frames[torch.from_numpy(perm).cuda()].contiguous()
+    d1, fc1 = det.detect(shuffled, n)
+    assert len(d1) == n
+    assert body(d1).tobytes() == body(d0[perm]).tobytes()
+    assert np.asarray(fc1).tobytes() == np.asarray(fc0[perm]).tobytes()
+    del shuffled
+    d2, fc2 = det.detect(frames[n // 2:], n // 2)
+    assert body(d2).tobytes() == body(d0[n // 2:]).tobytes() and np.asarray(fc2).tobytes() == np.asarray(fc0[n // 2:]).tobytes()
+    det.submit(frames, n)
+    det.submit(frames[n // 2:], n // 2)
+    d3, _ = det.collect()
+    d4, _ = det.collect()
+    assert np.asarray(d3).tobytes() == np.asarray(d0).tobytes() and body(d4).tobytes() == body(d0[n // 2:]).tobytes()
+    det.close()
+
+
 def test_record_tables_packed_on_device(torch_cuda):
     """rcc_set_record_tables: the table the ranks exchange is packed on the device by the detector (csrc/k_records.hip);
     it must equal the host form of the same layout (dist.pack) built from the records detect() returns -- every field,
