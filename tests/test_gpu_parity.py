@@ -927,6 +927,47 @@ def test_full_batch_properties_1080p(torch_cuda):
     det.close()
 
 
+def test_full_batch_properties_tags_1080p(torch_cuda):
+    """the configs[4]-style workload at the bench's size -- 1024 frames of 1920x1080 with 24 fiducials each -- through the same
+    oracle-free properties: the batch in a random order gives the same records per frame, the second half alone gives the second half,
+    the streamed form the synchronous call's bytes; at least 99 % of the 24 576 tags come back, each once per frame, hamming 0."""
+    torch = torch_cuda
+    n, gx, gy = 1024, 6, 4
+    cfg = _make(w=1920, h=1080, B=n)
+    fam = abi.load_family()
+    abi.set_fiducial_target(cfg, fam, tag_size=0.10, max_targets=gx * gy)
+    (hx, hy), _, ids = synth.fiducial_grid_layout(gx, gy, cfg.tag_size)
+    sp = abi.default_synth_params()
+    sp.fid_grid_x, sp.fid_grid_y, sp.fid_gap_permille = gx, gy, 500
+    det = api.Detector(cfg)
+    poses = synth.sample_poses(n, cfg, z_range=(1.0, 2.0), max_tilt_deg=40, half_extent_m=(hx, hy))
+    frames = torch.empty((n, cfg.frame_bytes), dtype=torch.uint8, device="cuda:0")
+    for s0 in range(0, n, 64):
+        det.synth_render(sp, poses[s0:s0 + 64], frames[s0:s0 + 64], first_index=s0)
+    torch.cuda.synchronize()
+    d0, _ = det.detect(frames, n, want_corners=False)
+    assert len(d0) >= 0.99 * n * gx * gy and (d0.hamming == 0).all() and set(np.unique(d0.id)) <= set(int(i) for i in ids)
+    key = d0.frame.astype(np.int64) * 1000 + d0.id
+    assert len(np.unique(key)) == len(key)                       # no tag twice in a frame
+    def per_frame(d, order=None):
+        """records grouped by frame (frame index removed), optionally for the frames in `order`"""
+        a = np.array(d, copy=True)
+        fr = a["frame"].copy()
+        a["frame"] = 0
+        groups = {int(f): a[fr == f].tobytes() for f in np.unique(fr)}
+        return [groups.get(int(f), b"") for f in (order if order is not None else range(n))]
+    rng = np.random.default_rng(6)
+    perm = rng.permutation(n)
+    d1, _ = det.detect(frames[torch.from_numpy(perm).cuda()].contiguous(), n, want_corners=False)
+    assert per_frame(d1) == per_frame(d0, perm)
+    d2, _ = det.detect(frames[n // 2:], n // 2, want_corners=False)
+    assert per_frame(d2)[:n // 2] == per_frame(d0, range(n // 2, n))
+    det.submit(frames, n)
+    d3, _ = det.collect()
+    assert np.asarray(d3).tobytes() == np.asarray(d0).tobytes()
+    det.close()
+
+
 def test_record_tables_packed_on_device(torch_cuda):
     """rcc_set_record_tables: the table the ranks exchange is packed on the device by the detector (csrc/k_records.hip);
     it must equal the host form of the same layout (dist.pack) built from the records detect() returns -- every field,
