@@ -330,6 +330,12 @@ def trace_summary(tr, B, world=1):
     if st:
         out["stage_ms_mean"] = {k: sum(x[k] for x in st) / len(st) for k in st[0]}
         out["stage_ms_median"] = {k: statistics.median(x[k] for x in st) for k in st[0]}
+        out["stage_ms_max"] = {k: max(x[k] for x in st) for k in st[0]}
+        allst = tr.get("stages") or []
+        if w and len(allst) == len(w) and allst[w.index(max(w))]:
+            # which stage a slow step lost its time in (one step of ~200 on this pool shows the one-wave-per-frame lattice + pose
+            # kernel taking 1.4 ms instead of 0.17: a device-side hiccup, no host cause in the counters)
+            out["slowest_step"] = {"index": w.index(max(w)), "wall_ms": max(w), "stages": allst[w.index(max(w))]}
     return out
 
 
