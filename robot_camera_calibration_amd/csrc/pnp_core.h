@@ -33,6 +33,14 @@
 #else
 #define RCC_NI
 #endif
+// the whole solve is inlined into every kernel that calls it (device builds): left to the compiler, the wave-per-target instantiation
+// -- three call sites -- stayed a FUNCTION: its arguments and results went through scratch memory, its prologue saved the caller's
+// registers there, and the lattice + pose kernel was the only kernel of the step with a scratch allocation
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RCC_SOLVE_INLINE __attribute__((always_inline)) inline
+#else
+#define RCC_SOLVE_INLINE inline
+#endif
 
 #ifndef RCC_DIST_PLUMB_BOB
 #define RCC_DIST_NONE 0
@@ -1194,7 +1202,7 @@ struct ParAccum {
 
 // whole solve; Par = SerialPar: one thread per target; Par = WavePar: one wavefront per target
 template <class Par>
-RCC_HD inline int solve_pnp(const Par& par, const Pts& p, const Cam& cm_in, int dist_model, double rvec[3], double tvec[3], double* rms, int* iters)
+RCC_HD RCC_SOLVE_INLINE int solve_pnp(const Par& par, const Pts& p, const Cam& cm_in, int dist_model, double rvec[3], double tvec[3], double* rms, int* iters)
 {
   Cam cm = cm_in;
   const bool has_dist = (dist_model == RCC_DIST_PLUMB_BOB);
