@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Helper of tests/test_experiments_library.py (not a test module): runs in a child process whose RCC_LIBRARY points at
 librcc_hip_exp.so and checks the measurement-only forms of the threshold + corner pass that only that library carries --
-the two-kernel variant 3 (band sweep + k_dense_runs on the active rows), the gang form of k_dense_wave and the 128 x 8 ingest
-tiles of rounds 1-3 -- for bit-identity
+the two-kernel variant 3 (band sweep + k_dense_runs on the active rows), the gang form of k_dense_wave, the 128 x 8 ingest
+tiles of rounds 1-3 and the lattice + pose kernel overlapped with the next batch's ingest pass -- for bit-identity
 with the forms the product library runs.  Prints one digest per geometry of the default form's outputs; the parent compares
 them with the product library's on the same frames."""
 import hashlib
@@ -70,6 +70,17 @@ def digest_default(torch, abi, api, synth, kind, w, h, n, exp):
                 assert d1.tobytes() == d0.tobytes() and f1.tobytes() == f0.tobytes()
                 assert (img1["bin"] == img0["bin"]).all() and (img1["cand_count"] == img0["cand_count"]).all()
             det.set_dense_gang(0, 0)
+        if kind == "bgr":
+            # the lattice + pose kernel of a streamed batch on a stream of its own, under the next batch's ingest pass (rcc_set_tail_overlap):
+            # five submissions, one batch ahead -- the records are the synchronous call's, byte for byte
+            det.set_tail_overlap(1)
+            det.submit(frames, n)
+            for k in range(5):
+                if k < 4:
+                    det.submit(frames, n)
+                d1, _ = det.collect()
+                assert np.asarray(d1).tobytes() == np.asarray(d0).tobytes(), "tail overlap: streamed batch %d differs" % k
+            det.set_tail_overlap(0)
     det.close()
     return hsh.hexdigest()
 
