@@ -35,7 +35,7 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)     # the first ~5 steps after start-up run 2-10 % slower than the steady state
-    ap.add_argument("--warmup", type=int, default=5)     # (scratch/t_steps.py): defaults long enough to measure the latter
+    ap.add_argument("--warmup", type=int, default=20)    # (scratch/t_steps.py): defaults long enough to measure the latter
     ap.add_argument("--batch", type=int, default=1024, help="frames per rank per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
