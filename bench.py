@@ -34,7 +34,7 @@ PCIE_GBS = 63.0                # MI355X_MICROARCH.md: PCIe Gen5 x16 (spec)
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)     # the first ~5 steps after start-up run 2-10 % slower than the steady state
+    ap.add_argument("--steps", type=int, default=40)     # the first ~5 steps after start-up run 2-10 % slower than the steady state
     ap.add_argument("--warmup", type=int, default=20)    # (scratch/t_steps.py): defaults long enough to measure the latter
     ap.add_argument("--batch", type=int, default=1024, help="frames per rank per step")
     ap.add_argument("--width", type=int, default=1920)
